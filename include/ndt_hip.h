@@ -1,0 +1,217 @@
+/*
+ * ndt_hip.h -- C ABI of libndt_hip.so, the MI355X (gfx950) ray-trace core for ndt.
+ *
+ * This library replaces exactly one thing in the reference: the body of
+ *     int render_image(scene *scn, char *name, ..., int width, int height, int samples,
+ *                      stereo_mode mode, int threads, ..., int max_optic_depth, ...)
+ * (reference ndt.c:900), i.e. the loop nest render_lines_thread (ndt.c:803) ->
+ * render_line (ndt.c:735) -> render_pixel (ndt.c:578) -> get_pixel_color (ndt.c:456) ->
+ * get_ray_color (ndt.c:329) / apply_lights (ndt.c:71) -> trace_kd (object.c:683) ->
+ * kd_tree_intersect (kd-tree.c:570) -> trace (object.c:692) -> obj->intersect (objects/ *.c).
+ *
+ * The boundary is plain C: pointers, sizes, ints and doubles.  A scene crosses it as an
+ * `ndt_flat_scene`: the reference's pointer-rich `scene` / `object` / `kd_tree_t` graph
+ * flattened into index-linked arrays (INTEGRATION.md shows the ~150-line flattening stub a
+ * maintainer adds next to render_image).  All reals are IEEE double, as in the reference.
+ *
+ * Error convention: every entry point returns 0 on success and a negative NDT_E_* code on
+ * failure; ndt_hip_last_error() gives the message.  The reference's exit(1)-on-error habit
+ * (object.c:233-236) is deliberately not carried into the library.
+ */
+#ifndef NDT_HIP_H
+#define NDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDT_HIP_ABI_VERSION 1
+
+/* Dimensions the gfx950 kernels are instantiated for.  The reference accepts any N >= 3
+ * (ndt.c:1450 `-d`); BASELINE.json's configs span 3..8. */
+#define NDT_MIN_DIMS 3
+#define NDT_MAX_DIMS 8
+#define NDT_MAX_LIGHTS 64
+
+#define NDT_OK              0
+#define NDT_E_INVALID      -1   /* malformed scene / argument */
+#define NDT_E_UNSUPPORTED  -2   /* valid for the reference, but not for the device path */
+#define NDT_E_DEVICE       -3   /* HIP runtime failure */
+#define NDT_E_NOMEM        -4
+#define NDT_E_STATE        -5   /* call out of order (no scene uploaded, ...) */
+
+/* Object kinds = the reference's built-in plugins (objects/ *.c `type_name`). */
+enum ndt_object_type {
+    NDT_OBJ_SPHERE    = 0,  /* objects/sphere.c    */
+    NDT_OBJ_HPLANE    = 1,  /* objects/hplane.c    */
+    NDT_OBJ_HDISK     = 2,  /* objects/hdisk.c     */
+    NDT_OBJ_CYLINDER  = 3,  /* objects/cylinder.c  */
+    NDT_OBJ_HCYLINDER = 4,  /* objects/hcylinder.c */
+    NDT_OBJ_ORTHOTOPE = 5,  /* objects/orthotope.c */
+    NDT_OBJ_HCUBE     = 6,  /* objects/hcube.c     */
+    NDT_OBJ_HFACET    = 7,  /* objects/hfacet.c    */
+    NDT_OBJ_FACET     = 8,  /* objects/facet.c     */
+    NDT_OBJ_TYPE_COUNT = 9
+};
+
+/* Same numbering as the reference's light_type enum (scene.h:23-31). */
+enum ndt_light_type {
+    NDT_LIGHT_AMBIENT     = 0,
+    NDT_LIGHT_POINT       = 1,
+    NDT_LIGHT_DIRECTIONAL = 2,
+    NDT_LIGHT_SPOT        = 3,
+    NDT_LIGHT_DISK        = 4,  /* area lights need the RNG path: NDT_E_UNSUPPORTED for now */
+    NDT_LIGHT_RECT        = 5
+};
+
+/* One light (reference `light`, scene.h:36-49).  pos/dir are offsets, in doubles, into
+ * ndt_flat_scene.vecs; -1 when the light has none. */
+typedef struct ndt_flat_light {
+    int32_t type;
+    int32_t pos_off;
+    int32_t dir_off;
+    int32_t _pad;
+    double  red, green, blue;
+    double  angle;              /* spot cone half-angle, degrees (ndt.c:204) */
+} ndt_flat_light;
+
+/* One object (reference `object`, object.h:23-74) with its API-level parameters as the scene
+ * wrote them (object_add_pos/dir/size/flag).  Ray-invariant data the plugins derive lazily in
+ * their prepare() is recomputed inside the library.
+ *
+ * Objects [0, n_items) are the kd items in kd id order (kd-tree.c:448); the per-ray visit
+ * mask (kd-tree.c:600) is indexed by that position.  Objects >= n_items are nested
+ * primitives owned by a composite (`parent` >= 0): the orthotope faces an hcube builds in
+ * add_faces (objects/hcube.c:34).  Clusters never appear: object_kdlist_add flattens them
+ * (object.c:636-643). */
+typedef struct ndt_flat_object {
+    int32_t type;               /* enum ndt_object_type */
+    int32_t transparent;        /* object.h:24 */
+    int32_t parent;             /* -1 for kd items */
+    int32_t n_pos,  pos_off;    /* pos[i] = vecs + pos_off + i*dims */
+    int32_t n_dir,  dir_off;
+    int32_t n_size, size_off;   /* into sizes[] */
+    int32_t n_flag, flag_off;   /* into flags[] */
+    int32_t n_obj,  obj_off;    /* children: obj_refs[obj_off .. obj_off+n_obj) are object indices */
+    int32_t bounds_center_off;  /* into vecs[] */
+    double  bounds_radius;      /* >0: gate with bounding sphere; <=0: no gate (object.c:618-624) */
+    double  red, green, blue;
+    double  red_r, green_r, blue_r;
+    double  refract_index;
+} ndt_flat_object;
+
+/* One kd-tree node (reference kd_node_t, kd-tree.h:52-59).  Interior: dim >= 0, left/right
+ * are node indices.  Leaf: dim < 0, items are leaf_refs[first .. first+num). */
+typedef struct ndt_flat_kdnode {
+    int32_t dim;
+    int32_t num;
+    int32_t left, right;
+    int32_t first;
+    int32_t _pad;
+    double  boundary;
+} ndt_flat_kdnode;
+
+typedef struct ndt_flat_scene {
+    int32_t abi_version;        /* NDT_HIP_ABI_VERSION */
+    int32_t dims;
+
+    /* pools */
+    const double  *vecs;     int64_t n_vecs;      /* doubles */
+    const double  *sizes;    int64_t n_sizes;
+    const int32_t *flags;    int64_t n_flags;
+    const int32_t *obj_refs; int64_t n_obj_refs;
+
+    /* camera after camera_aim (camera.c:132), before render_image's dirX *= W/H (ndt.c:926);
+     * offsets into vecs.  Only CAMERA_NORMAL (camera.c:557-575) is on the device path. */
+    int32_t cam_type;
+    int32_t cam_pos_off, cam_img_orig_off, cam_dir_x_off, cam_dir_y_off;
+    double  cam_focal_distance;
+
+    /* scene colours: scn->ambient (scene.h:59) and bg_* (scene.h:60) */
+    double ambient[3];
+    double background[4];
+
+    const ndt_flat_light  *lights;  int32_t n_lights;
+    const ndt_flat_object *objects; int32_t n_objects; int32_t n_items;
+
+    /* kd-tree (kd-tree.h:63-71): node 0 is the root */
+    const ndt_flat_kdnode *kd_nodes;  int32_t n_kd_nodes;
+    const int32_t         *leaf_refs; int32_t n_leaf_refs;   /* object indices (< n_items) */
+    const int32_t         *inf_refs;  int32_t n_inf;         /* infinite objects, kd-tree.c:459 */
+    int32_t bb_lower_off, bb_upper_off;                      /* root AABB, into vecs */
+} ndt_flat_scene;
+
+/* Arguments of one render_image call (ndt.c:900).  Rows are dealt cyclically exactly like the
+ * reference's threads/MPI_ROW split (ndt.c:812-820): this call renders image rows
+ * j = row_begin, row_begin+row_step, ... < height, and output row k holds image row
+ * row_begin + k*row_step.  row_begin=0,row_step=1 renders the whole frame. */
+typedef struct ndt_render_params {
+    int32_t width, height;
+    int32_t max_optic_depth;    /* `-l`, default 128 (ndt.c:1413) */
+    int32_t samples;            /* must be 1: the deterministic path */
+    int32_t row_begin, row_step;
+    int32_t specular;           /* 1 = specular_enabled (ndt.c:41) */
+    int32_t profile;            /* 1 = bracket trace kernels with hipEvents (fills *_ms below) */
+} ndt_render_params;
+
+typedef struct ndt_render_stats {
+    /* rays actually traced on the device: one per unique trace_kd query */
+    int64_t rays_primary, rays_secondary, rays_shadow;
+    /* rays the reference executes for the same pixels: every pixel's ray tree times the
+     * adaptive loop's repeat count k (ndt.c:488) */
+    int64_t rays_ref_equiv;
+    int32_t levels;             /* ray-tree depth reached */
+    int32_t trace_launches;     /* launches of the trace kernel */
+    double  trace_ms;           /* summed device time of those launches (profile=1) */
+    double  frame_ms;           /* device time of the whole call (profile=1) */
+    int64_t node_capacity;      /* ray-tree nodes the workspace holds */
+} ndt_render_stats;
+
+typedef struct ndt_hip_ctx ndt_hip_ctx;
+
+/* Create a context on HIP device `device` with its own stream.  Fails with NDT_E_DEVICE when
+ * no gfx950 device is usable -- there is no CPU fallback in this library. */
+int ndt_hip_create(int device, ndt_hip_ctx **out);
+int ndt_hip_destroy(ndt_hip_ctx *ctx);
+
+/* Validate the scene, derive the plugins' prepare() data, lay it out for the device and copy
+ * it to HBM.  Replaces the per-frame state render_image reads: `scn` and the global `kdtree`
+ * (ndt.c:68). */
+int ndt_hip_upload_scene(ndt_hip_ctx *ctx, const ndt_flat_scene *scene);
+
+/* render_image (ndt.c:900) for the rows selected by `p`.  `rgba` receives
+ * rows*width*4 doubles laid out like the reference's dbl image (image.c:126: r,g,b,a per
+ * pixel, row-major).  _device: `rgba` is a device pointer on ctx's device (stays in HBM);
+ * plain: `rgba` is host memory. */
+int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats);
+int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, ndt_render_stats *stats);
+
+/* Batch of trace_kd queries (object.c:683) against the uploaded scene -- the unit the
+ * known-answer tests pin.  o, v: n*dims doubles (ray-major); dist_limit: n doubles with the
+ * reference's meaning (<0 closest hit, 0 any hit, >0 first hit within limit; ndt.c:177-189).
+ * Outputs (host): obj[n] = object index or -1; hit, normal: n*dims doubles, zero when obj<0. */
+int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n, const double *o, const double *v,
+                       const double *dist_limit, int32_t *obj, double *hit, double *normal);
+
+/* Quantise a double image like the reference does at save time: pixel_d2c (image.h:36-39),
+ * (unsigned char)(sqrt(clamp01(x))*255) per channel.  d_rgba: device, n_pixels*4 doubles;
+ * d_rgba8: device, n_pixels*4 bytes. */
+int ndt_hip_quantize_device(ndt_hip_ctx *ctx, const void *d_rgba, void *d_rgba8, int64_t n_pixels);
+
+/* Number of rows a (row_begin,row_step) shard of a `height`-row image holds. */
+int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step);
+
+/* The stream the context launches on (a hipStream_t), for callers that time with their own
+ * events or order other work against it. */
+void *ndt_hip_stream(ndt_hip_ctx *ctx);
+int ndt_hip_synchronize(ndt_hip_ctx *ctx);
+
+const char *ndt_hip_last_error(void);
+int ndt_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDT_HIP_H */
