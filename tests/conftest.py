@@ -1,0 +1,96 @@
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from ndt_amd import load_scene, RenderParams, RenderStats  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Oracle:
+    """ctypes face of oracle/libndt_oracle.so -- the CPU checker (test infrastructure only)."""
+
+    def __init__(self):
+        path = os.path.join(ROOT, "oracle", "libndt_oracle.so")
+        src = os.path.join(ROOT, "oracle", "ndt_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True)
+        self.lib = C.CDLL(path)
+        self.lib.ndt_oracle_render.restype = C.c_int
+        self.lib.ndt_oracle_trace_rays.restype = C.c_int
+
+    def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1):
+        from ndt_amd import shard_rows
+        rows = shard_rows(height, row_begin, row_step)
+        p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, 0)
+        st = RenderStats()
+        out = np.zeros((rows, width, 4), dtype=np.float64)
+        threads = threads or min(8, os.cpu_count() or 1)
+        rc = self.lib.ndt_oracle_render(fs.byref(), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st),
+                                        C.c_int(threads), C.c_int(1 if literal else 0))
+        assert rc == 0, "oracle render failed rc=%d" % rc
+        return out, st
+
+    def trace(self, fs, rays):
+        d = fs.dims
+        n = rays.shape[0]
+        o = np.ascontiguousarray(rays[:, :d])
+        v = np.ascontiguousarray(rays[:, d:2 * d])
+        lim = np.ascontiguousarray(rays[:, 2 * d])
+        obj = np.zeros(n, dtype=np.int32)
+        hit = np.zeros((n, d))
+        nrm = np.zeros((n, d))
+        rc = self.lib.ndt_oracle_trace_rays(fs.byref(), C.c_int64(n), o.ctypes.data_as(C.c_void_p),
+                                            v.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p),
+                                            obj.ctypes.data_as(C.c_void_p), hit.ctypes.data_as(C.c_void_p),
+                                            nrm.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return obj, hit, nrm
+
+    def quantize(self, rgba):
+        flat = np.ascontiguousarray(rgba, dtype=np.float64)
+        out = np.zeros(flat.shape, dtype=np.uint8)
+        self.lib.ndt_oracle_quantize(flat.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                     C.c_int64(flat.size))
+        return out
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return Oracle()
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.meta = json.load(f)
+        self.scene = load_scene(os.path.join(GOLDEN, self.meta["scene_file"]))
+        self.data = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.width, self.height, self.depth = self.meta["width"], self.meta["height"], self.meta["depth"]
+
+
+_golden_cache = {}
+
+
+def golden(name):
+    if name not in _golden_cache:
+        _golden_cache[name] = Golden(name)
+    return _golden_cache[name]
+
+
+SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4d", "c5_hypercube4d",
+               "c5_hypercube5d"]
+KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d"]
+FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the COMPILED REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle ref          # compiles the reference where it lies -> oracle/_ref/
+    python tests/golden/make_golden.py [case ...]
+
+For every case this drives oracle/_ref/ndt_ref_shim (oracle/ref_shim.c) to
+  * flatten the prepared scene the reference built          -> <case>.ndtscene.gz
+  * render it with the reference's own render_image          -> <case>.npz : fb (H,W,4) float64,
+                                                                or rgba8 (H,W,4) uint8 for the
+                                                                full-resolution cases (pixel_d2c)
+  * answer seeded trace_kd queries                           -> <case>.npz : kat_in, kat_out
+  * count trace_kd calls during the render                   -> <case>.json
+The fixtures are data (inputs + expected outputs); no reference source text is stored.
+"""
+import gzip
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from ndt_amd import load_scene  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+SHIM = os.path.join(REF, "ndt_ref_shim")
+
+# name -> scene .so, dims, WxH, -l depth, what to keep
+CASES = {
+    # BASELINE.json configs[0] at reduced size: double framebuffer
+    "c1_hypercube3d": dict(scene="hypercube", dims=3, res=(96, 96), depth=128, fb=True, kat=2048),
+    # configs[1], configs[2] at reduced size: double framebuffers + known-answer rays
+    "c2_balls4d": dict(scene="balls", dims=4, res=(128, 72), depth=128, fb=True, kat=4096),
+    "c3_random4d": dict(scene="random", dims=4, res=(128, 72), depth=4, fb=True, kat=4096),
+    # configs[4] family at reduced size; 5-D exercises the odd-N lane-pair dot order
+    "c5_hypercube4d": dict(scene="hypercube", dims=4, res=(64, 36), depth=128, fb=True, kat=1024),
+    "c5_hypercube5d": dict(scene="hypercube", dims=5, res=(48, 27), depth=128, fb=True, kat=1024),
+    # an animated frame: rotated hypercube, different tree
+    "c1_hypercube3d_f37": dict(scene="hypercube", dims=3, res=(64, 64), depth=128, fb=True, kat=0, frame=37),
+    # full BASELINE resolution, 8-bit (what the reference writes to PNG)
+    "c2_balls4d_1080p": dict(scene="balls", dims=4, res=(1920, 1080), depth=128, fb=False, rgba8=True, kat=0,
+                             share_scene="c2_balls4d"),
+    "c3_random4d_1080p": dict(scene="random", dims=4, res=(1920, 1080), depth=4, fb=False, rgba8=True, kat=0,
+                              share_scene="c3_random4d"),
+}
+
+
+def run_shim(args):
+    cmd = [SHIM, "--objects", os.path.join(REF, "objects")] + args
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    info = {}
+    m = re.search(r"ref_shim: render_s ([0-9.]+) threads (\d+)", out)
+    if m:
+        info["ref_render_s"] = float(m.group(1))
+        info["ref_threads"] = int(m.group(2))
+    m = re.search(r"ref_shim: rays_closest (\d+) rays_shadow (\d+) rays_total (\d+)", out)
+    if m:
+        info["rays_closest"], info["rays_shadow"], info["rays_total"] = (int(m.group(i)) for i in (1, 2, 3))
+    return info
+
+
+def make_kat_rays(fs, n, seed):
+    """Seeded query rays: camera-like, interior random, and shadow-like with limits."""
+    rng = np.random.default_rng(seed)
+    d = fs.dims
+    cam = fs.vec(fs.cam["pos"])
+    lo, hi = fs.vec(fs.bb["lower"]), fs.vec(fs.bb["upper"])
+    if not np.all(np.isfinite(lo)) or np.any(lo > hi):
+        lo, hi = -10 * np.ones(d), 10 * np.ones(d)
+    rays = np.zeros((n, 2 * d + 1))
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:      # from the camera into the scene box
+            o = cam
+            tgt = lo + rng.random(d) * (hi - lo)
+            v = tgt - o
+            lim = -1.0
+        elif kind == 1:    # between two random points of the (slightly grown) box
+            o = lo - 1 + rng.random(d) * (hi - lo + 2)
+            tgt = lo + rng.random(d) * (hi - lo)
+            v = tgt - o
+            lim = -1.0
+        elif kind == 2:    # any-hit (directional-light shadow rays use limit 0, ndt.c:184)
+            o = lo + rng.random(d) * (hi - lo)
+            v = rng.standard_normal(d)
+            lim = 0.0
+        else:              # point-light style: positive limit (ndt.c:187-188)
+            o = lo - 2 + rng.random(d) * (hi - lo + 4)
+            tgt = lo + rng.random(d) * (hi - lo)
+            v = tgt - o
+            lim = float(np.linalg.norm(v)) * rng.uniform(0.3, 1.2)
+        if i % 16 == 5:    # axis-parallel components exercise the v_inv clamp (kd-tree.c:583-588)
+            v = v.copy()
+            v[rng.integers(0, d)] = 0.0
+        nv = np.linalg.norm(v)
+        if nv < 1e-9:
+            v = np.ones(d)
+            nv = np.linalg.norm(v)
+        rays[i, :d] = o
+        rays[i, d:2 * d] = v / nv
+        rays[i, 2 * d] = lim
+    return rays
+
+
+def generate(name, case):
+    print("==", name, flush=True)
+    w, h = case["res"]
+    frame = case.get("frame", 0)
+    threads = str(os.cpu_count() or 1)
+    base = ["--scene", os.path.join(REF, "scenes", case["scene"] + ".so"), "--dims", str(case["dims"]),
+            "--frame", str(frame), "--res", "%dx%d" % (w, h), "--threads", threads, "--depth", str(case["depth"])]
+    meta = dict(name=name, scene=case["scene"], dims=case["dims"], width=w, height=h, depth=case["depth"],
+                frame=frame, generator="tests/golden/make_golden.py via oracle/ref_shim.c")
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        scene_txt = os.path.join(tmp, "scene.txt")
+        # pass 1: scene only
+        run_shim(base + ["--tmp", tmp, "--scene-out", scene_txt, "--no-render"])
+        fs = load_scene(scene_txt)
+        share = case.get("share_scene")
+        if share:
+            # same scene as another case: verify and reference it instead of storing a copy
+            with gzip.open(os.path.join(HERE, share + ".ndtscene.gz"), "rt") as g:
+                if g.read() != open(scene_txt).read():
+                    raise SystemExit("scene of %s differs from %s" % (name, share))
+            meta["scene_file"] = share + ".ndtscene.gz"
+        else:
+            with open(scene_txt, "rb") as src, open(os.path.join(HERE, name + ".ndtscene.gz"), "wb") as raw:
+                with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as dst:
+                    dst.write(src.read())
+            meta["scene_file"] = name + ".ndtscene.gz"
+        meta["objects"] = fs.type_histogram()
+        meta["kd_nodes"] = len(fs.kd_nodes)
+        # pass 2: render (+ known answers)
+        args = base + ["--tmp", tmp, "--fb-out", os.path.join(tmp, "fb.bin")]
+        if case["kat"]:
+            rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"])
+            rays.tofile(os.path.join(tmp, "rays.bin"))
+            args += ["--rays-in", os.path.join(tmp, "rays.bin"), "--rays-out", os.path.join(tmp, "kat.bin")]
+        meta.update(run_shim(args))
+        fb = np.fromfile(os.path.join(tmp, "fb.bin")).reshape(h, w, 4)
+        if case.get("fb"):
+            arrays["fb"] = fb
+        if case.get("rgba8"):
+            # pixel_d2c (image.h:36-39): the byte the reference's PNG/JPEG writer stores
+            arrays["rgba8"] = (np.sqrt(np.maximum(0.0, np.minimum(1.0, fb))) * 255).astype(np.uint8)
+            meta["fb_max"] = float(fb[..., :3].max())
+        if case["kat"]:
+            d = case["dims"]
+            arrays["kat_in"] = rays
+            arrays["kat_out"] = np.fromfile(os.path.join(tmp, "kat.bin")).reshape(-1, 2 + 2 * d)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("   ", {k: v for k, v in meta.items() if k.startswith("rays") or k.startswith("ref_")}, flush=True)
+
+
+def main():
+    if not os.path.exists(SHIM):
+        raise SystemExit("build the reference first: make -C oracle ref")
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        generate(name, CASES[name])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""Pin the CPU oracle (oracle/ndt_oracle.c) against outputs of the compiled reference.
+
+The fixtures under tests/golden/ were produced by the reference's own render_image /
+trace_kd (tests/golden/make_golden.py).  The oracle has to reproduce them BIT FOR BIT:
+same glibc libm, no FMA, SSE lane-pair dot order.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_framebuffer_bit_exact(oracle, name):
+    g = golden(name)
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth)
+    ref = g.data["fb"]
+    assert out.shape == ref.shape
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    # the reference's trace_kd counter (ld --wrap in oracle/ref_shim.c) vs the oracle's replay of
+    # the adaptive re-sampling loop (ndt.c:488)
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+    assert st.rays_primary == g.width * g.height
+
+
+@pytest.mark.parametrize("name", ["c1_hypercube3d_f37", "c5_hypercube4d"])
+def test_literal_resampling_is_identical(oracle, name):
+    """Tracing all k identical samples like the reference does changes nothing but run time."""
+    g = golden(name)
+    a, sa = oracle.render(g.scene, g.width, g.height, g.depth, literal=False)
+    b, sb = oracle.render(g.scene, g.width, g.height, g.depth, literal=True)
+    assert np.array_equal(a, b)
+    assert sa.rays_ref_equiv == sb.rays_ref_equiv == g.meta["rays_total"]
+
+
+@pytest.mark.parametrize("name", KAT_CASES)
+def test_trace_kd_known_answers(oracle, name):
+    g = golden(name)
+    rays, want = g.data["kat_in"], g.data["kat_out"]
+    d = g.scene.dims
+    obj, hit, nrm = oracle.trace(g.scene, rays)
+    assert np.array_equal(obj, want[:, 1].astype(np.int32))
+    assert np.array_equal((obj >= 0).astype(np.float64), want[:, 0])
+    assert np.array_equal(hit, want[:, 2:2 + d])
+    assert np.array_equal(nrm, want[:, 2 + d:2 + 2 * d])
+    # the vectors must actually exercise hits and misses, and every limit kind
+    assert (obj >= 0).any() and (obj < 0).any()
+    for lim_kind in (rays[:, 2 * d] < 0, rays[:, 2 * d] == 0, rays[:, 2 * d] > 0):
+        assert lim_kind.sum() > 100
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_full_resolution_8bit(oracle, name):
+    """BASELINE.json configs[1]/[2] at 1920x1080: every byte the reference would write."""
+    g = golden(name)
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth)
+    got = oracle.quantize(out)
+    assert np.array_equal(got, g.data["rgba8"])
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+def test_row_sharding_matches_full_frame(oracle):
+    g = golden("c3_random4d")
+    full, _ = oracle.render(g.scene, g.width, g.height, g.depth)
+    for step in (2, 3):
+        for begin in range(step):
+            part, _ = oracle.render(g.scene, g.width, g.height, g.depth, row_begin=begin, row_step=step)
+            assert np.array_equal(part, full[begin::step])
