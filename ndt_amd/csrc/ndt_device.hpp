@@ -1,0 +1,889 @@
+// ndt_device.hpp -- device-side ray math for the gfx950 tracer, templated on the dimension N.
+//
+// Everything here is the per-ray arithmetic of the reference's hot path, written for one
+// ray per lane of a 64-wide wavefront: vectors are register arrays double[N] with N a
+// compile-time constant (every loop unrolls, every index is static), the scene is one
+// read-only blob of 8-byte words that a kernel addresses either in LDS or in global memory,
+// and nothing allocates (the reference mallocs ~6 temporaries per ray).
+//
+// Arithmetic contract (same as the oracle): IEEE double, compiled with -ffp-contract=off,
+// dot products summed in the SSE2 lane-pair order of vectNd.h:215-227.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NDT_EPS   (1e-4)                    /* object.h:15 */
+#define NDT_EPS2  ((NDT_EPS) * (NDT_EPS))   /* object.h:17 */
+#define NDT_INV_EPS2 (1.0 / (NDT_EPS2))     /* kd-tree.c:480 */
+#define NDT_DBL_MAX 1.7976931348623157e308
+#define NDT_PI 3.14159265358979323846       /* M_PI */
+
+#define NDT_DEV __device__ __forceinline__
+
+// object header flag bits (word 0, low int)
+#define NDT_F_TYPE_MASK   0xff
+#define NDT_F_GATE        0x100     /* bounds.radius > 0: bounding-sphere gate (object.c:618) */
+#define NDT_F_INF_ENDS    0x200     /* cylinder.c:87 / hcylinder.c:107 */
+#define NDT_F_USE_NORMALS 0x400     /* hfacet.c:283 */
+#define NDT_F_TRANSPARENT 0x800
+
+enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
+// light_type numbering of the reference, scene.h:23-31
+enum { NDT_LIGHT_AMBIENT_ = 0, NDT_LIGHT_POINT_ = 1, NDT_LIGHT_DIRECTIONAL_ = 2, NDT_LIGHT_SPOT_ = 3 };
+
+// Offsets (in 8-byte words) of the sections of the scene blob.  Passed by value as a kernel
+// argument, so every field is wave-uniform and lives in SGPRs.
+struct SceneDesc {
+    int n_items, n_objects, n_kd_nodes, n_inf, n_lights;
+    int off_kd;        // 2 words per node: {int dim, int right} {double boundary | int first, int num}
+    int off_leaf;      // int32 pairs: object indices of all leaves
+    int off_inf;       // int32 pairs: infinite objects
+    int off_hdr;       // 2 words per object: {int flags, int param_off} {int aux0, int aux1}
+    int off_bs;        // (N+2) words per object: center[N], radius, radius^2
+    int off_bb;        // lower[N], upper[N]
+    int off_child;     // int32 pairs: nested primitives of composites
+    int off_params;    // per-type parameter records
+    int trace_words;   // everything above: what the trace kernel stages in LDS
+    int off_mat;       // 8 words per object: rgb, reflect rgb, refract index, transparent
+    int off_lights;    // per light: {int type,0}, r,g,b, angle, pos[N], dir[N]
+    int off_cam;       // pos[N], img_orig[N], dir_x[N], dir_y[N], focal, ambient[3], background[4]
+    int total_words;
+    int mask_words;    // 64-bit words of visit mask per ray (kd-tree.c:600)
+};
+
+// ------------------------------------------------------------------ vectNd.h
+
+template <int N> NDT_DEV double v_dot(const double (&a)[N], const double (&b)[N])
+{
+    // vectNd_dot, vectNd.h:215-227: lane 0 sums even components, lane 1 odd components
+    double s0 = a[0] * b[0];
+    double s1 = a[1] * b[1];
+#pragma unroll
+    for (int i = 2; i < N; i += 2) {
+        s0 = s0 + a[i] * b[i];
+        if (i + 1 < N) s1 = s1 + a[i + 1] * b[i + 1];
+    }
+    return s0 + s1;
+}
+template <int N> NDT_DEV void v_add(const double (&a)[N], const double (&b)[N], double (&r)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = a[i] + b[i];
+}
+template <int N> NDT_DEV void v_sub(const double (&a)[N], const double (&b)[N], double (&r)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = a[i] - b[i];
+}
+template <int N> NDT_DEV void v_scale(const double (&a)[N], double s, double (&r)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = a[i] * s;
+}
+template <int N> NDT_DEV void v_copy(double (&d)[N], const double (&s)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = s[i];
+}
+template <int N> NDT_DEV void v_zero(double (&d)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = 0.0;
+}
+template <int N> NDT_DEV double v_len(const double (&a)[N]) { return sqrt(v_dot<N>(a, a)); }
+template <int N> NDT_DEV void v_unitize(double (&a)[N])
+{
+    // vectNd_unitize, vectNd.h:323
+    double len = v_len<N>(a);
+    if (len > NDT_EPS || len < -NDT_EPS) v_scale<N>(a, 1.0 / len, a);
+}
+template <int N> NDT_DEV double v_dist(const double (&a)[N], const double (&b)[N])
+{
+    double d[N];
+    v_sub<N>(a, b, d);
+    return v_len<N>(d);
+}
+template <int N> NDT_DEV void v_proj_unit(const double (&v)[N], const double (&onto)[N], double (&r)[N])
+{
+    double ab = v_dot<N>(v, onto);
+    v_scale<N>(onto, ab, r);
+}
+template <int N> NDT_DEV void v_proj(const double (&v)[N], const double (&onto)[N], double (&r)[N])
+{
+    double bb = v_dot<N>(onto, onto);
+    double ab = v_dot<N>(v, onto);
+    v_scale<N>(onto, ab / bb, r);
+}
+template <int N> NDT_DEV double v_angle(const double (&a)[N], const double (&b)[N])
+{
+    // vectNd_angle, vectNd.c:64
+    double dp = v_dot<N>(a, b);
+    double l1 = v_len<N>(a);
+    double l2 = v_len<N>(b);
+    double div = l1 * l2;
+    if (fabs(div) > NDT_EPS) return acos(dp / div);
+    return -1;
+}
+template <int N> NDT_DEV double v_sum(const double (&a)[N])
+{
+    // vectNd_dot(a, ones), hfacet.c:241: same lane order, multiplications by 1.0 are exact
+    double s0 = a[0];
+    double s1 = a[1];
+#pragma unroll
+    for (int i = 2; i < N; i += 2) {
+        s0 = s0 + a[i];
+        if (i + 1 < N) s1 = s1 + a[i + 1];
+    }
+    return s0 + s1;
+}
+template <int N> NDT_DEV void v_reflect(const double (&u)[N], const double (&nrm)[N], double (&res)[N], double mag)
+{
+    // vectNd_reflect, vectNd.c:101
+    double nnu[N];
+    double nu = v_dot<N>(nrm, u);
+    double nn = v_dot<N>(nrm, nrm);
+    v_scale<N>(nrm, (1 + mag) * nu / nn, nnu);
+    v_sub<N>(u, nnu, res);
+}
+template <int N> NDT_DEV void v_refract(const double (&u)[N], double (&nrm)[N], double (&res)[N], double index)
+{
+    // vectNd_refract, vectNd.c:119 (unitizes nrm in place, vectNd.c:155)
+    double rev_u[N], rev_n[N], un[N], np[N], ref_n[N], ref_p[N];
+    v_scale<N>(u, -1, rev_u);
+    v_scale<N>(nrm, -1, rev_n);
+    double un_dot = v_dot<N>(rev_u, nrm);
+    double theta_in;
+    if (un_dot < 0) {
+        index = 1 / index;
+        theta_in = v_angle<N>(rev_u, rev_n);
+    } else {
+        theta_in = v_angle<N>(rev_u, nrm);
+    }
+    double theta_out;
+    double sin_out = sin(theta_in) / index;
+    if (sin_out <= 1.0)
+        theta_out = asin(sin_out);
+    else
+        theta_out = NDT_PI - theta_in;
+    v_unitize<N>(rev_n);
+    v_unitize<N>(nrm);
+    v_proj_unit<N>(u, rev_n, un);
+    v_sub<N>(u, un, np);
+    v_unitize<N>(np);
+    double rn = cos(theta_out);
+    double rp = sin(theta_out);
+    if (un_dot < 0)
+        v_scale<N>(nrm, rn, ref_n);
+    else
+        v_scale<N>(rev_n, rn, ref_n);
+    v_scale<N>(np, rp, ref_p);
+    v_add<N>(ref_n, ref_p, res);
+}
+// a[i] for a runtime i without spilling the register array to scratch
+template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
+{
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) r = (i == k) ? a[k] : r;
+    return r;
+}
+
+// ------------------------------------------------------------------ scene blob access
+
+// The blob pointer is either LDS or global; all reads go through these so that the
+// compiler sees one base pointer + index and can pick ds_read / global_load.
+NDT_DEV int blob_int(const double *blob, int word, int half)
+{
+    return reinterpret_cast<const int *>(blob)[2 * word + half];
+}
+NDT_DEV int blob_int_at(const double *blob, int word_off, int idx)   // idx-th int32 of a packed section
+{
+    return reinterpret_cast<const int *>(blob)[2 * word_off + idx];
+}
+template <int N> NDT_DEV void blob_vec(const double *blob, int word, double (&r)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = blob[word + i];
+}
+
+// ------------------------------------------------------------------ object plugins
+//
+// isect<N, FULL>: one primitive (everything except hcube).  Returns hit/no-hit; `res` is
+// always the hit point when it returns true; `normal` is only produced when FULL.
+
+template <int N> NDT_DEV bool within_axes(const double *blob, int p0, int rec, int m, const double (&point)[N])
+{
+    // hcylinder.c:101-130 / orthotope.c:122-148.  Axis record i at rec + i*(N+3): axis[N], length, AdA, BdA
+    double pos[N], Bc[N];
+    blob_vec<N>(blob, p0, pos);
+    v_sub<N>(point, pos, Bc);
+    for (int i = 0; i < m; ++i) {
+        int a = rec + i * (N + 3);
+        double ax[N];
+        blob_vec<N>(blob, a, ax);
+        double scale = v_dot<N>(Bc, ax);
+        scale = scale / blob[a + N + 1];
+        if (scale < -NDT_EPS || scale > blob[a + N] + NDT_EPS) return false;
+    }
+    return true;
+}
+
+template <int N>
+NDT_DEV void axes_quadratic(const double *blob, int p0, int rec, int m, const double (&o)[N], const double (&v)[N],
+                            double &qa, double &qb, double &qc)
+{
+    // hcylinder.c:159-185 / orthotope.c:175-199
+    double sA[N], sum_A[N], P[N], Q[N], pos[N];
+    v_zero<N>(sum_A);
+    for (int i = 0; i < m; ++i) {
+        int a = rec + i * (N + 3);
+        double ax[N];
+        blob_vec<N>(blob, a, ax);
+        double AdA = blob[a + N + 1];
+        double VdA = v_dot<N>(v, ax);
+        v_scale<N>(ax, VdA / AdA, sA);
+        v_add<N>(sum_A, sA, sum_A);
+    }
+    v_sub<N>(sum_A, v, P);
+    v_zero<N>(sum_A);
+    for (int i = 0; i < m; ++i) {
+        int a = rec + i * (N + 3);
+        double ax[N];
+        blob_vec<N>(blob, a, ax);
+        double AdA = blob[a + N + 1];
+        double BdA = blob[a + N + 2];
+        double OdA = v_dot<N>(o, ax);
+        v_scale<N>(ax, (OdA - BdA) / AdA, sA);
+        v_add<N>(sum_A, sA, sum_A);
+    }
+    blob_vec<N>(blob, p0, pos);
+    v_sub<N>(pos, o, Q);
+    v_add<N>(Q, sum_A, Q);
+    qa = v_dot<N>(P, P);
+    qb = v_dot<N>(P, Q);
+    qb *= 2;
+    qc = v_dot<N>(Q, Q);
+}
+
+template <int N>
+NDT_DEV void axes_normal(const double *blob, int p0, int rec, int m, const double (&res)[N], double (&normal)[N])
+{
+    // hcylinder.c:222-237 / orthotope.c:280-295
+    double P[N], Q[N], sA[N], pos[N];
+    blob_vec<N>(blob, p0, pos);
+    v_sub<N>(res, pos, P);
+    v_zero<N>(Q);
+    for (int i = 0; i < m; ++i) {
+        double ax[N];
+        blob_vec<N>(blob, rec + i * (N + 3), ax);
+        v_proj<N>(P, ax, sA);
+        v_add<N>(Q, sA, Q);
+    }
+    v_sub<N>(P, Q, normal);
+}
+
+template <int N, bool FULL>
+NDT_DEV bool isect(const double *blob, const SceneDesc &sd, int prim, const double (&o)[N], const double (&v)[N],
+                   double (&res)[N], double (&normal)[N])
+{
+    const int h = sd.off_hdr + 2 * prim;
+    const int flags = blob_int(blob, h, 0);
+    const int type = flags & NDT_F_TYPE_MASK;
+    const int p = sd.off_params + blob_int(blob, h, 1);
+    switch (type) {
+    case T_SPHERE: {
+        // sphere.c:57-112.  params: center[N], r^2
+        double c[N], oc[N];
+        blob_vec<N>(blob, p, c);
+        v_sub<N>(o, c, oc);
+        double oc_len2 = v_dot<N>(oc, oc);
+        double voc = v_dot<N>(v, oc);
+        double desc = (voc * voc) - oc_len2 + blob[p + N];
+        if (desc < 0.0) return false;
+        double desc_root = sqrt(desc);
+        double d = -(voc + desc_root);
+        if (d < NDT_EPS) {
+            d = desc_root - voc;
+            if (d < NDT_EPS) return false;
+        }
+        v_scale<N>(v, d, res);
+        v_add<N>(o, res, res);
+        if (FULL) v_sub<N>(res, c, normal);
+        return true;
+    }
+    case T_HPLANE:
+    case T_HDISK: {
+        // hplane.c:39-75, hdisk.c:61-85.  params: pos[N], dir[N], radius
+        double pos[N], nrm[N], pl[N];
+        blob_vec<N>(blob, p, pos);
+        blob_vec<N>(blob, p + N, nrm);
+        double d = -1;
+        v_sub<N>(pos, o, pl);
+        double pln = v_dot<N>(pl, nrm);
+        double ln = v_dot<N>(v, nrm);
+        if (ln > NDT_EPS || ln < -NDT_EPS) d = pln / ln;
+        if (d < NDT_EPS) return false;
+        v_scale<N>(v, d, pl);
+        v_add<N>(o, pl, res);
+        if (type == T_HDISK) {
+            double dist = v_dist<N>(res, pos);
+            if (dist > blob[p + 2 * N] || dist < 0) return false;
+        }
+        if (FULL) v_copy<N>(normal, nrm);
+        return true;
+    }
+    case T_CYLINDER: {
+        // cylinder.c:104-210.  params: pos0[N], axis[N], length, AdA, BdA, radius
+        double Be[N], A[N], sA[N], X[N], Y[N], tmp[N];
+        blob_vec<N>(blob, p, Be);
+        blob_vec<N>(blob, p + N, A);
+        const double length = blob[p + 2 * N], AdA = blob[p + 2 * N + 1], BdA = blob[p + 2 * N + 2];
+        const double size0 = blob[p + 2 * N + 3];
+        double VdA = v_dot<N>(v, A);
+        double OdA = v_dot<N>(o, A);
+        double Vaaa = VdA / AdA;
+        double BOaa = (BdA - OdA) / AdA;
+        v_scale<N>(A, Vaaa, sA);
+        v_sub<N>(v, sA, Y);
+        v_sub<N>(o, Be, tmp);
+        v_scale<N>(A, BOaa, sA);
+        v_add<N>(tmp, sA, X);
+        double qa = v_dot<N>(Y, Y);
+        double qb = v_dot<N>(Y, X);
+        qb *= 2;
+        double qc = v_dot<N>(X, X);
+        qc -= size0 * size0;
+        double det = qb * qb - 4 * qa * qc;
+        if (det <= 0) return false;
+        double detRoot = sqrt(det);
+        double t1 = (-qb + detRoot) / (2 * qa);
+        double t2 = (-qb - detRoot) / (2 * qa);
+        bool ret = false;
+        const bool inf_ends = (flags & NDT_F_INF_ENDS) != 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            double t = pass == 0 ? t2 : t1;
+            if (!ret && t > NDT_EPS) {
+                v_scale<N>(v, t, sA);
+                v_add<N>(o, sA, res);
+                if (inf_ends) {
+                    ret = true;
+                } else {
+                    // between_ends, cylinder.c:88-102
+                    double Bc[N];
+                    v_sub<N>(res, Be, Bc);
+                    double scale = v_dot<N>(Bc, A);
+                    if (scale > 0 && scale < length) ret = true;
+                }
+            }
+        }
+        if (ret && FULL) {
+            v_sub<N>(res, Be, X);
+            double nCdA = v_dot<N>(A, X);
+            v_scale<N>(A, nCdA / AdA, Y);
+            v_sub<N>(X, Y, normal);
+        }
+        return ret;
+    }
+    case T_HCYLINDER: {
+        // hcylinder.c:132-244.  params: pos0[N], radius, then m axis records
+        const int m = blob_int(blob, h + 1, 1);
+        const int rec = p + N + 1;
+        double qa, qb, qc;
+        axes_quadratic<N>(blob, p, rec, m, o, v, qa, qb, qc);
+        const double radius = blob[p + N];
+        qc -= radius * radius;
+        double det = qb * qb - 4 * qa * qc;
+        if (det < 0.0) return false;
+        double detRoot = sqrt(det);
+        double t1 = (-qb + detRoot) / (2 * qa);
+        double t2 = (-qb - detRoot) / (2 * qa);
+        bool ret = false;
+        const bool inf_ends = (flags & NDT_F_INF_ENDS) != 0;
+        double sA[N];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            double t = pass == 0 ? t2 : t1;
+            if (!ret && t > NDT_EPS) {
+                v_scale<N>(v, t, sA);
+                v_add<N>(o, sA, res);
+                if (inf_ends || within_axes<N>(blob, p, rec, m, res)) ret = true;
+            }
+        }
+        if (ret && FULL) axes_normal<N>(blob, p, rec, m, res, normal);
+        return ret;
+    }
+    case T_ORTHOTOPE: {
+        // orthotope.c:150-302.  params: pos0[N], pad, then m basis records
+        const int m = blob_int(blob, h + 1, 1);
+        const int rec = p + N + 1;
+        double qa, qb, qc;
+        axes_quadratic<N>(blob, p, rec, m, o, v, qa, qb, qc);
+        qc -= NDT_EPS;
+        double det = qb * qb - 4 * qa * qc;
+        bool ret = false;
+        double sA[N];
+        if (det >= 0.0 && fabs(qa) > NDT_EPS) {
+            double detRoot = sqrt(det);
+            double half_inv_qa = 0.5 / qa;
+            double t1 = (-qb + detRoot) * half_inv_qa;
+            double t2 = (-qb - detRoot) * half_inv_qa;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                double t = pass == 0 ? t2 : t1;
+                if (!ret && t > NDT_EPS) {
+                    v_scale<N>(v, t, sA);
+                    v_add<N>(o, sA, res);
+                    if (within_axes<N>(blob, p, rec, m, res)) ret = true;
+                }
+            }
+        }
+        if (!ret) {
+            double t = -1.0;
+            if (fabs(qa) < NDT_EPS) {
+                if (fabs(qb) < NDT_EPS)   // sic: orthotope.c:238-241
+                    t = -qc / qb;
+                else
+                    t = -1.0;
+            } else {
+                t = -qb / (2 * qa);
+            }
+            if (t < NDT_EPS) return false;
+            double dist = qa * t * t + qb * t + qc;
+            if (fabs(dist) > NDT_EPS) return false;
+            v_scale<N>(v, t, sA);
+            v_add<N>(o, sA, res);
+            if (within_axes<N>(blob, p, rec, m, res)) ret = true;
+        }
+        if (ret && FULL) axes_normal<N>(blob, p, rec, m, res, normal);
+        return ret;
+    }
+    case T_HFACET: {
+        // hfacet.c:211-310.  params: v0[N], unit_edge0[N], edge_perp[N], x2,y2,x3,y3, dir[3][N]
+        double v0[N], ue0[N], perp[N], R[N], vE0[N], vE2[N], Q[N], oP0[N];
+        blob_vec<N>(blob, p, v0);
+        blob_vec<N>(blob, p + N, ue0);
+        blob_vec<N>(blob, p + 2 * N, perp);
+        v_proj_unit<N>(v, ue0, vE0);
+        v_proj_unit<N>(v, perp, vE2);
+        v_add<N>(vE0, vE2, R);
+        v_sub<N>(R, v, R);
+        double Rv = v_sum<N>(R);
+        if (fabs(Rv) < NDT_EPS) return false;
+        v_sub<N>(o, v0, oP0);
+        v_proj_unit<N>(oP0, ue0, vE0);
+        v_proj_unit<N>(oP0, perp, vE2);
+        v_add<N>(vE0, vE2, Q);
+        v_sub<N>(Q, oP0, Q);
+        double Qv = v_sum<N>(Q);
+        double t = -Qv / Rv;
+        if (!(t > NDT_EPS)) return false;
+        v_scale<N>(v, t, res);
+        v_add<N>(o, res, res);
+        // get_barycentric, hfacet.c:156-199
+        double C[N];
+        v_sub<N>(res, v0, C);
+        const double x1 = 0, y1 = 0;
+        double xp = v_dot<N>(ue0, C);
+        double yp = v_dot<N>(perp, C);
+        const double x2 = blob[p + 3 * N], y2 = blob[p + 3 * N + 1], x3 = blob[p + 3 * N + 2], y3 = blob[p + 3 * N + 3];
+        double l1 = ((y2 - y3) * (xp - x3) + (x3 - x2) * (yp - y3)) / ((y2 - y3) * (x1 - x3) + (x3 - x2) * (y1 - y3));
+        double l2 = ((y3 - y1) * (xp - x3) + (x1 - x3) * (yp - y3)) / ((y2 - y3) * (x1 - x3) + (x3 - x2) * (y1 - y3));
+        double l3 = 1 - l1 - l2;
+        if (l1 < -NDT_EPS || l1 > 1 + NDT_EPS) return false;
+        if (l2 < -NDT_EPS || l2 > 1 + NDT_EPS) return false;
+        if (l3 < -NDT_EPS || l3 > 1 + NDT_EPS) return false;
+        if (FULL) {
+            if (flags & NDT_F_USE_NORMALS) {
+                double nd[N];
+                v_zero<N>(normal);
+                blob_vec<N>(blob, p + 3 * N + 4, nd);
+                v_scale<N>(nd, l1, R);
+                v_add<N>(normal, R, normal);
+                blob_vec<N>(blob, p + 4 * N + 4, nd);
+                v_scale<N>(nd, l2, R);
+                v_add<N>(normal, R, normal);
+                blob_vec<N>(blob, p + 5 * N + 4, nd);
+                v_scale<N>(nd, l3, R);
+                v_add<N>(normal, R, normal);
+            } else {
+                // hfacet_point_in_plane, hfacet.c:119-144
+                double D[N], U[N], V[N];
+                v_sub<N>(o, v0, D);
+                v_proj_unit<N>(D, ue0, U);
+                v_proj_unit<N>(D, perp, V);
+                v_add<N>(U, V, R);
+                v_add<N>(R, v0, R);
+                v_sub<N>(o, R, normal);
+                v_unitize<N>(normal);
+            }
+        }
+        return true;
+    }
+    case T_FACET: {
+        // facet.c:166-269.  params: pos[3][N], basis[2][N], AdA[2], BdA[2], angle[3], dir0[N]
+        double pos1[N], P[N], sA[N], sum_A[N], Q[N];
+        blob_vec<N>(blob, p + N, pos1);
+        v_zero<N>(sum_A);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double b[N];
+            blob_vec<N>(blob, p + 3 * N + i * N, b);
+            double VdA = v_dot<N>(v, b);
+            double AdA = blob[p + 5 * N + i];
+            v_scale<N>(b, VdA / AdA, sA);
+            v_add<N>(sum_A, sA, sum_A);
+        }
+        v_sub<N>(sum_A, v, P);
+        v_zero<N>(sum_A);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double b[N];
+            blob_vec<N>(blob, p + 3 * N + i * N, b);
+            double OdA = v_dot<N>(o, b);
+            double BdA = blob[p + 5 * N + 2 + i];
+            double AdA = blob[p + 5 * N + i];
+            v_scale<N>(b, (OdA - BdA) / AdA, sA);
+            v_add<N>(sum_A, sA, sum_A);
+        }
+        v_sub<N>(pos1, o, Q);
+        v_add<N>(Q, sum_A, Q);
+        double qa = v_dot<N>(P, P);
+        double qb = v_dot<N>(P, Q);
+        qb *= 2;
+        double qc = v_dot<N>(Q, Q);
+        double t = -1.0;
+        if (fabs(qa) < NDT_EPS) {
+            if (fabs(qb) < NDT_EPS)
+                t = -qc / qb;
+            else
+                t = -1.0;
+        } else {
+            t = -qb / (2 * qa);
+        }
+        if (t < NDT_EPS) return false;
+        double dist = qa * t * t + qb * t + qc;
+        if (fabs(dist) > NDT_EPS) return false;
+        v_scale<N>(v, t, sA);
+        v_add<N>(o, sA, res);
+        // inside_edges, facet.c:148-164
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = (i + 1) % 3;
+            double pi[N], pj[N], a[N], b[N];
+            blob_vec<N>(blob, p + i * N, pi);
+            blob_vec<N>(blob, p + j * N, pj);
+            v_sub<N>(res, pi, a);
+            v_sub<N>(pj, pi, b);
+            double angle = v_angle<N>(a, b);
+            if (angle > blob[p + 5 * N + 4 + i]) return false;
+        }
+        if (FULL) blob_vec<N>(blob, p + 5 * N + 7, normal);
+        return true;
+    }
+    default:
+        return false;
+    }
+}
+
+// vect_bounding_sphere_intersect, bounding.c:34-85
+template <int N>
+NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, const double (&o)[N], const double (&v)[N],
+                          double min_dist)
+{
+    const int b = sd.off_bs + obj * (N + 2);
+    double c[N], oc[N];
+    blob_vec<N>(blob, b, c);
+    v_sub<N>(o, c, oc);
+    double oc_len2 = v_dot<N>(oc, oc);
+    if (min_dist > 0) {
+        double min_dist_r = min_dist + blob[b + N];
+        if (oc_len2 > min_dist_r * min_dist_r) return false;
+    }
+    double voc = v_dot<N>(v, oc);
+    double voc2 = voc * voc;
+    double desc = voc2 - oc_len2 + blob[b + N + 1];
+    if (desc < 0.0 || (voc > 0.0 && voc2 > desc)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ trace / kd-tree
+
+// Per-ray visit mask (the reference callocs obj_num bytes per ray, kd-tree.c:600).
+// MW > 0: MW 64-bit words in registers, indexed by unrolled selects.
+// MW == 0: `ext` points at this lane's words in a global scratch slab (large scenes).
+template <int MW> struct VisitMask {
+    unsigned long long w[MW > 0 ? MW : 1];
+    unsigned long long *ext;
+    int ext_stride;
+    NDT_DEV void clear(int words)
+    {
+        if (MW > 0) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) w[i] = 0ull;
+        } else {
+            for (int i = 0; i < words; ++i) ext[(size_t)i * ext_stride] = 0ull;
+        }
+    }
+    // returns true when `id` was already visited; marks it otherwise
+    NDT_DEV bool test_and_set(int id)
+    {
+        const unsigned long long bit = 1ull << (id & 63);
+        const int word = id >> 6;
+        if (MW > 0) {
+            bool seen = false;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (i == word) {
+                    seen = (w[i] & bit) != 0ull;
+                    w[i] |= bit;
+                }
+            }
+            return seen;
+        } else {
+            unsigned long long cur = ext[(size_t)word * ext_stride];
+            if (cur & bit) return true;
+            ext[(size_t)word * ext_stride] = cur | bit;
+            return false;
+        }
+    }
+};
+
+// Result of one list scan (`trace`, object.c:692-747): the accepted object, the primitive
+// that produced the hit point (a face for an hcube, else the object itself), and min_dist.
+struct ListHit {
+    double min_dist;
+    int obj, prim;
+};
+
+// trace(), object.c:692-747, over objs = int section `sec` [first, first+cnt).
+// Nested hcube faces (hcube.c:236-250) run as an inner list with the same body, so the
+// primitive intersector is instantiated once.
+template <int N, int MW, bool USE_MASK>
+NDT_DEV ListHit trace_list(const double *blob, const SceneDesc &sd, int sec, int first, int cnt, VisitMask<MW> &mask,
+                           const double (&o)[N], const double (&v)[N], double dist_limit)
+{
+    ListHit best;
+    best.min_dist = -1;
+    best.obj = -1;
+    best.prim = -1;
+    // inner (hcube) list state
+    bool in_sub = false;
+    int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
+    double sub_min = -1;
+    int i = 0;
+    while (true) {
+        int prim = -1, owner = -1;
+        double gate_min = -1;
+        bool have_result = false, ret = false;
+        double dist = -1;
+        int hit_prim = -1;
+        if (in_sub) {
+            if (sub_i == sub_end) {
+                // nested trace finished: hcube.intersect returns its verdict (hcube.c:241-248)
+                in_sub = false;
+                have_result = true;
+                ret = (sub_min >= 0);
+                dist = sub_min;     // == |o - res| of the accepted face, same arithmetic
+                owner = sub_owner;
+                hit_prim = sub_prim;
+                prim = -1;
+            } else {
+                prim = blob_int_at(blob, sd.off_child, sub_i++);
+                owner = sub_owner;
+                gate_min = sub_min;
+            }
+        } else {
+            if (i == cnt) break;
+            const int id = blob_int_at(blob, sec, first + i);
+            ++i;
+            if (USE_MASK) {
+                if (mask.test_and_set(id)) continue;        // object.c:707-713
+            }
+            const int h = sd.off_hdr + 2 * id;
+            const int flags = blob_int(blob, h, 0);
+            if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
+                // vect_object_intersect gate on the hcube itself (object.c:618-624)
+                if ((flags & NDT_F_GATE) && !bsphere_gate<N>(blob, sd, id, o, v, best.min_dist)) continue;
+                in_sub = true;
+                sub_owner = id;
+                sub_i = blob_int(blob, h + 1, 0);
+                sub_end = sub_i + blob_int(blob, h + 1, 1);
+                sub_min = -1;
+                sub_prim = -1;
+                continue;
+            }
+            prim = id;
+            owner = id;
+            gate_min = best.min_dist;
+        }
+        if (!have_result) {
+            const int flags = blob_int(blob, sd.off_hdr + 2 * prim, 0);
+            bool ok = true;
+            if (flags & NDT_F_GATE) ok = bsphere_gate<N>(blob, sd, prim, o, v, gate_min);
+            if (ok) {
+                double res[N], nrm[N];
+                ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
+                if (ok) dist = v_dist<N>(o, res);       // object.c:721
+            }
+            if (in_sub) {
+                // inner trace(): dist_limit = -1, no mask (hcube.c:241)
+                if (ok && dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
+                    sub_min = dist;
+                    sub_prim = prim;
+                }
+                continue;
+            }
+            ret = ok;
+            hit_prim = prim;
+        }
+        if (ret) {
+            if (dist > NDT_EPS && (dist + NDT_EPS < best.min_dist || best.min_dist < 0)) {   // object.c:722
+                best.min_dist = dist;
+                best.obj = owner;
+                best.prim = hit_prim;
+            }
+            if (dist_limit == 0.0 || dist < dist_limit) break;                                 // object.c:730
+        }
+    }
+    return best;
+}
+
+#define NDT_KD_STACK 40
+
+// trace_kd (object.c:683) = kd_tree_intersect (kd-tree.c:570-625) with kd_node_intersect
+// (kd-tree.c:482-568) unrolled onto an explicit stack.  The recursion visits `near`, then
+// re-checks `*t_ptr > gate` before `far`; the stack entry carries that gate.
+template <int N, int MW>
+NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
+                      const double (&v)[N], double dist_limit, int &out_obj, int &out_prim)
+{
+    double v_inv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double v_i = v[i], r;
+        if (v_i < NDT_EPS2 && v_i >= 0.0)
+            r = NDT_INV_EPS2;
+        else if (v_i > -NDT_EPS2 && v_i <= 0.0)
+            r = -NDT_INV_EPS2;
+        else
+            r = 1.0 / v_i;
+        v_inv[i] = r;
+    }
+    // infinite objects first, linear, unmasked (kd-tree.c:594)
+    double t = NDT_DBL_MAX;
+    ListHit inf = trace_list<N, MW, false>(blob, sd, sd.off_inf, 0, sd.n_inf, mask, o, v, dist_limit);
+    const bool ret_inf = inf.min_dist >= 0;
+    if (inf.min_dist > NDT_EPS) t = inf.min_dist;       // object.c:736
+    out_obj = inf.obj;
+    out_prim = inf.prim;
+
+    // aabb_intersect on the root box, kd-tree.c:84-127
+    double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
+    bool box = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (box) {
+            double v_i = v[i], o_i = o[i];
+            if (!(fabs(v_i) < NDT_EPS2)) {
+                double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
+                double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
+                if (tl_i > tu_i) {
+                    double tmp = tl_i;
+                    tl_i = tu_i;
+                    tu_i = tmp;
+                }
+                if (tl_i > tl) tl = tl_i;
+                if (tu_i < tu) tu = tu_i;
+                if (tu < -NDT_EPS) box = false;
+            }
+        }
+    }
+    if (box) {
+        tl -= NDT_EPS;
+        tu += NDT_EPS;
+        box = (tu >= -NDT_EPS) && (tl <= tu);
+    }
+    if (!box || sd.n_kd_nodes <= 0) return;
+
+    mask.clear(sd.mask_words);
+    double lt = NDT_DBL_MAX;
+    int l_obj = -1, l_prim = -1;
+    bool lret = false;
+
+    int st_node[NDT_KD_STACK];
+    double st_tl[NDT_KD_STACK], st_tu[NDT_KD_STACK], st_gate[NDT_KD_STACK];
+    int sp = 0;
+    int node = 0;
+    double ntl = tl, ntu = tu;
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            node = st_node[sp];
+            ntl = st_tl[sp];
+            ntu = st_tu[sp];
+            if (!(lt > st_gate[sp])) continue;      // the `*t_ptr > ...` test before the far call
+        }
+        have = false;
+        if (ntu < 0.0) continue;                    // kd-tree.c:490
+        const int k = sd.off_kd + 2 * node;
+        const int dim = blob_int(blob, k, 0);
+        if (dim < 0) {
+            // leaf: trace() over its items (kd-tree.c:497-519)
+            const int first = blob_int(blob, k + 1, 0), num = blob_int(blob, k + 1, 1);
+            if (num > 0) {
+                ListHit lh = trace_list<N, MW, true>(blob, sd, sd.off_leaf, first, num, mask, o, v, dist_limit);
+                if (lh.min_dist >= 0) {
+                    lret = true;
+                    if (lh.min_dist < lt) {         // `ret && t < *t_ptr`; t is set whenever ret (dist > EPS)
+                        lt = lh.min_dist;
+                        l_obj = lh.obj;
+                        l_prim = lh.prim;
+                    }
+                }
+            }
+            continue;
+        }
+        const double boundary = blob[k + 1];
+        int near = node + 1, far = blob_int(blob, k, 1);    // preorder: left child follows its parent
+        const double v_inv_i = v_pick<N>(v_inv, dim);
+        const double o_i = v_pick<N>(o, dim);
+        if (v_inv_i < NDT_EPS2) {
+            int tmp = near;
+            near = far;
+            far = tmp;
+        }
+        if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
+            const double tp = (boundary - o_i) * v_inv_i;
+            // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before pushing
+            // the far child is safe; the test that counts is repeated at pop time, after the
+            // near subtree has been searched, exactly like the second `if` at kd-tree.c:552.
+            if (ntu < tp - NDT_EPS && lt > ntl) {
+                node = near; have = true;                       // near only, same interval
+            } else if (ntl > tp + NDT_EPS && lt > ntl) {
+                node = far; have = true;                        // far only, same interval
+            } else {
+                if (lt > tp) {
+                    st_node[sp] = far; st_tl[sp] = tp - NDT_EPS; st_tu[sp] = ntu; st_gate[sp] = tp; ++sp;
+                }
+                if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have = true; }
+            }
+        } else {
+            // plane parallel to the ray (unreachable for finite v_inv, kept for fidelity: kd-tree.c:555-565)
+            const bool go_far = o_i > boundary - NDT_EPS;
+            const bool go_near = o_i < boundary + NDT_EPS && lt > ntl;
+            if (go_far) {
+                st_node[sp] = far; st_tl[sp] = ntl; st_tu[sp] = ntu; st_gate[sp] = ntl; ++sp;
+            }
+            if (go_near) { node = near; have = true; }
+        }
+    }
+    if (lret) {
+        if (!ret_inf || (lt > NDT_EPS && lt + NDT_EPS < t)) {   // kd-tree.c:612
+            out_obj = l_obj;
+            out_prim = l_prim;
+        }
+    }
+}

@@ -1,0 +1,984 @@
+// ndt_host.hip -- host side of libndt_hip.so: the C ABI of include/ndt_hip.h.
+//
+//   ndt_hip_upload_scene : validate an ndt_flat_scene, derive what the reference's plugins
+//                          derive lazily in prepare() (objects/ *.c), lay everything out as
+//                          one blob of 8-byte words and copy it to HBM.
+//   ndt_hip_render*      : render_image (ndt.c:900) as a bounce-synchronous wavefront tracer.
+//
+// There is no CPU fallback here: without a usable HIP device every entry point fails with
+// NDT_E_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ndt_hip.h"
+#include "ndt_kernels.hpp"
+
+// ------------------------------------------------------------------ errors
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(NDT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+extern "C" const char *ndt_hip_last_error(void) { return g_err; }
+extern "C" int ndt_hip_abi_version(void) { return NDT_HIP_ABI_VERSION; }
+extern "C" int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step)
+{
+    if (row_step < 1 || row_begin < 0 || row_begin >= height) return 0;
+    return (height - row_begin + row_step - 1) / row_step;
+}
+
+// ------------------------------------------------------------------ context
+
+struct ndt_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    const NdtKernelTable *kt = nullptr;
+    int dims = 0;
+    bool have_scene = false;
+    SceneDesc sd{};
+    std::vector<double> blob;
+    double *d_blob = nullptr;
+    size_t d_blob_words = 0;
+    int tier = 0;
+    int n_shadow_lights = 0;
+    // workspace
+    Workspace ws{};
+    std::vector<void *> ws_allocs;
+    long long ws_dims = 0;
+    long long ws_slab_words = 0;
+    void *d_out = nullptr;          // staging for ndt_hip_render (host output)
+    size_t d_out_bytes = 0;
+    int *h_counters = nullptr;      // pinned
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static const NdtKernelTable *table_for(int dims)
+{
+    switch (dims) {
+    case 3: return ndt_kernel_table_3();
+    case 4: return ndt_kernel_table_4();
+    case 5: return ndt_kernel_table_5();
+    case 6: return ndt_kernel_table_6();
+    case 7: return ndt_kernel_table_7();
+    case 8: return ndt_kernel_table_8();
+    default: return nullptr;
+    }
+}
+
+extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
+{
+    if (!out) return fail(NDT_E_INVALID, "ndt_hip_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(NDT_E_DEVICE, "no HIP device available (%s); libndt_hip has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(NDT_E_INVALID, "device %d out of range (have %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NDT_E_DEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+    ndt_hip_ctx *ctx = new ndt_hip_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(NDT_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    e = hipHostMalloc((void **)&ctx->h_counters, 16 * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(NDT_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return NDT_OK;
+}
+
+static void free_workspace(ndt_hip_ctx *ctx)
+{
+    for (void *p : ctx->ws_allocs) (void)hipFree(p);
+    ctx->ws_allocs.clear();
+    memset(&ctx->ws, 0, sizeof(ctx->ws));
+    ctx->ws_slab_words = 0;
+    ctx->ws_dims = 0;
+}
+
+extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
+{
+    if (!ctx) return NDT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_workspace(ctx);
+    if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NDT_OK;
+}
+
+extern "C" void *ndt_hip_stream(ndt_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int ndt_hip_synchronize(ndt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(NDT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ host vector math (prepare)
+//
+// Same operation order as the reference's vectNd.h (SSE2 lane-pair dot).  This file is
+// compiled with -ffp-contract=off for host and device alike.
+
+static double h_dot(const double *a, const double *b, int n)
+{
+    double s0 = a[0] * b[0];
+    double s1 = a[1] * b[1];
+    for (int i = 2; i < n; i += 2) {
+        s0 = s0 + a[i] * b[i];
+        if (i + 1 < n) s1 = s1 + a[i + 1] * b[i + 1];
+    }
+    return s0 + s1;
+}
+static void h_sub(const double *a, const double *b, double *r, int n) { for (int i = 0; i < n; ++i) r[i] = a[i] - b[i]; }
+static void h_scale(const double *a, double s, double *r, int n) { for (int i = 0; i < n; ++i) r[i] = a[i] * s; }
+static double h_len(const double *a, int n) { return sqrt(h_dot(a, a, n)); }
+static void h_unitize(double *a, int n)
+{
+    double len = h_len(a, n);
+    if (len > NDT_EPS || len < -NDT_EPS) h_scale(a, 1.0 / len, a, n);
+}
+static double h_dist(const double *a, const double *b, int n)
+{
+    double d[NDT_MAX_DIMS];
+    h_sub(a, b, d, n);
+    return h_len(d, n);
+}
+static double h_angle3(const double *p1, const double *p2, const double *p3, int n)
+{
+    // vectNd_angle3 / vectNd_angle, vectNd.c:83 / :64
+    double a[NDT_MAX_DIMS], b[NDT_MAX_DIMS];
+    h_sub(p1, p2, a, n);
+    h_sub(p3, p2, b, n);
+    double dp = h_dot(a, b, n);
+    double div = h_len(a, n) * h_len(b, n);
+    if (fabs(div) > NDT_EPS) return acos(dp / div);
+    return -1;
+}
+
+// ------------------------------------------------------------------ scene validation + blob
+
+namespace {
+
+struct BlobBuilder {
+    std::vector<double> w;
+    int words() const { return (int)w.size(); }
+    int push(double x) { w.push_back(x); return words() - 1; }
+    int push_vec(const double *v, int n) { int at = words(); for (int i = 0; i < n; ++i) w.push_back(v[i]); return at; }
+    int push_ints(int a, int b)
+    {
+        double d;
+        int pair[2] = { a, b };
+        memcpy(&d, pair, sizeof(d));
+        w.push_back(d);
+        return words() - 1;
+    }
+    int push_int_list(const std::vector<int> &v)
+    {
+        int at = words();
+        for (size_t i = 0; i < v.size(); i += 2) push_ints(v[i], i + 1 < v.size() ? v[i + 1] : 0);
+        if (v.empty()) push_ints(0, 0);
+        return at;
+    }
+    void set_ints(int word, int a, int b)
+    {
+        int pair[2] = { a, b };
+        memcpy(&w[word], pair, sizeof(double));
+    }
+};
+
+bool vec_ok(const ndt_flat_scene *fs, int64_t off, int64_t count)
+{
+    return off >= 0 && count >= 0 && off + count * fs->dims <= fs->n_vecs;
+}
+
+} // namespace
+
+// Renumber the kd-tree in preorder (left child = parent + 1) and check it is a tree.
+static int kd_preorder(const ndt_flat_scene *fs, int node, int depth, std::vector<int> &order, std::vector<char> &seen,
+                       int &max_depth)
+{
+    if (node < 0 || node >= fs->n_kd_nodes) return fail(NDT_E_INVALID, "kd node index %d out of range", node);
+    if (seen[node]) return fail(NDT_E_INVALID, "kd node %d reached twice", node);
+    seen[node] = 1;
+    order.push_back(node);
+    if (depth > max_depth) max_depth = depth;
+    const ndt_flat_kdnode &k = fs->kd_nodes[node];
+    if (k.dim >= 0) {
+        if (k.dim >= fs->dims) return fail(NDT_E_INVALID, "kd node %d splits dimension %d of a %d-D scene", node, k.dim, fs->dims);
+        int rc = kd_preorder(fs, k.left, depth + 1, order, seen, max_depth);
+        if (rc) return rc;
+        rc = kd_preorder(fs, k.right, depth + 1, order, seen, max_depth);
+        if (rc) return rc;
+    } else {
+        if (k.num < 0 || k.first < 0 || (int64_t)k.first + k.num > fs->n_leaf_refs)
+            return fail(NDT_E_INVALID, "kd leaf %d item range out of bounds", node);
+        for (int i = 0; i < k.num; ++i) {
+            int id = fs->leaf_refs[k.first + i];
+            if (id < 0 || id >= fs->n_items) return fail(NDT_E_INVALID, "kd leaf %d lists object %d (n_items %d)", node, id, fs->n_items);
+        }
+    }
+    return NDT_OK;
+}
+
+static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
+{
+    const int n = fs->dims;
+    BlobBuilder b;
+    SceneDesc sd{};
+    sd.n_items = fs->n_items;
+    sd.n_objects = fs->n_objects;
+    sd.n_kd_nodes = fs->n_kd_nodes;
+    sd.n_inf = fs->n_inf;
+    sd.n_lights = fs->n_lights;
+    sd.mask_words = (fs->n_items + 63) / 64;
+    if (sd.mask_words < 1) sd.mask_words = 1;
+
+    // ---- kd nodes, preorder
+    std::vector<int> order;
+    std::vector<char> seen((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), 0);
+    int max_depth = 0;
+    if (fs->n_kd_nodes > 0) {
+        int rc = kd_preorder(fs, 0, 1, order, seen, max_depth);
+        if (rc) return rc;
+        if (max_depth > NDT_KD_STACK)
+            return fail(NDT_E_UNSUPPORTED, "kd-tree depth %d exceeds the traversal stack (%d)", max_depth, NDT_KD_STACK);
+    }
+    std::vector<int> new_index((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), -1);
+    for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+    sd.n_kd_nodes = (int)order.size();
+    std::vector<int> leaf_list;
+    sd.off_kd = b.words();
+    for (size_t i = 0; i < order.size(); ++i) {
+        const ndt_flat_kdnode &k = fs->kd_nodes[order[i]];
+        if (k.dim >= 0) {
+            if (new_index[k.left] != (int)i + 1) return fail(NDT_E_INVALID, "internal: preorder numbering");
+            b.push_ints(k.dim, new_index[k.right]);
+            b.push(k.boundary);
+        } else {
+            b.push_ints(-1, 0);
+            b.push_ints((int)leaf_list.size(), k.num);
+            for (int j = 0; j < k.num; ++j) leaf_list.push_back(fs->leaf_refs[k.first + j]);
+        }
+    }
+    sd.off_leaf = b.push_int_list(leaf_list);
+    std::vector<int> inf_list;
+    for (int i = 0; i < fs->n_inf; ++i) {
+        int id = fs->inf_refs[i];
+        if (id < 0 || id >= fs->n_items) return fail(NDT_E_INVALID, "infinite list names object %d (n_items %d)", id, fs->n_items);
+        inf_list.push_back(id);
+    }
+    sd.off_inf = b.push_int_list(inf_list);
+
+    // ---- object headers (filled after params are placed), bounding spheres, root box
+    sd.off_hdr = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        b.push_ints(0, 0);
+        b.push_ints(0, 0);
+    }
+    sd.off_bs = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        if (!vec_ok(fs, o.bounds_center_off, 1)) return fail(NDT_E_INVALID, "object %d: bounds centre out of range", i);
+        b.push_vec(fs->vecs + o.bounds_center_off, n);
+        b.push(o.bounds_radius);
+        b.push(o.bounds_radius * o.bounds_radius);      // bounding.c:22
+    }
+    if (!vec_ok(fs, fs->bb_lower_off, 1) || !vec_ok(fs, fs->bb_upper_off, 1)) return fail(NDT_E_INVALID, "root box out of range");
+    sd.off_bb = b.push_vec(fs->vecs + fs->bb_lower_off, n);
+    b.push_vec(fs->vecs + fs->bb_upper_off, n);
+
+    // ---- nested primitive lists
+    std::vector<int> child_list;
+    std::vector<int> child_first((size_t)(fs->n_objects > 0 ? fs->n_objects : 1), 0);
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        child_first[i] = (int)child_list.size();
+        if (o.type == NDT_OBJ_HCUBE) {
+            if (o.n_obj < 1) return fail(NDT_E_UNSUPPORTED, "object %d: hcube without faces (supply add_faces output)", i);
+            if (o.obj_off < 0 || (int64_t)o.obj_off + o.n_obj > fs->n_obj_refs) return fail(NDT_E_INVALID, "object %d: child range", i);
+            for (int k = 0; k < o.n_obj; ++k) {
+                int c = fs->obj_refs[o.obj_off + k];
+                if (c < 0 || c >= fs->n_objects || fs->objects[c].type == NDT_OBJ_HCUBE)
+                    return fail(NDT_E_INVALID, "object %d: bad nested primitive %d", i, c);
+                child_list.push_back(c);
+            }
+        }
+    }
+    sd.off_child = b.push_int_list(child_list);
+
+    // ---- per-type parameters = the plugins' prepare() output
+    sd.off_params = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        if (o.type < 0 || o.type >= NDT_OBJ_TYPE_COUNT) return fail(NDT_E_UNSUPPORTED, "object %d: unknown type %d", i, o.type);
+        if (!vec_ok(fs, o.pos_off, o.n_pos) || !vec_ok(fs, o.dir_off, o.n_dir)) return fail(NDT_E_INVALID, "object %d: vector range", i);
+        if (o.n_size < 0 || o.size_off < 0 || (int64_t)o.size_off + o.n_size > fs->n_sizes) return fail(NDT_E_INVALID, "object %d: size range", i);
+        if (o.n_flag < 0 || o.flag_off < 0 || (int64_t)o.flag_off + o.n_flag > fs->n_flags) return fail(NDT_E_INVALID, "object %d: flag range", i);
+        const double *pos = fs->vecs + o.pos_off;
+        const double *dir = fs->vecs + o.dir_off;
+        const double *size = fs->sizes + o.size_off;
+        const int *flag = fs->flags + o.flag_off;
+        int flags = o.type;
+        if (o.bounds_radius > 0) flags |= NDT_F_GATE;
+        if (o.transparent) flags |= NDT_F_TRANSPARENT;
+        int aux0 = 0, aux1 = 0;
+        const int p = b.words() - sd.off_params;
+        double tmp[NDT_MAX_DIMS], ax[NDT_MAX_DIMS];
+        auto need = [&](bool ok, const char *what) -> int {
+            return ok ? NDT_OK : fail(NDT_E_INVALID, "object %d: %s", i, what);
+        };
+        int rc = NDT_OK;
+        switch (o.type) {
+        case NDT_OBJ_SPHERE:        // sphere.c:18-32 (pow(r,2.0) == r*r)
+            if ((rc = need(o.n_pos >= 1 && o.n_size >= 1, "sphere needs 1 pos, 1 size"))) return rc;
+            b.push_vec(pos, n);
+            b.push(size[0] * size[0]);
+            break;
+        case NDT_OBJ_HPLANE:
+        case NDT_OBJ_HDISK:
+            if ((rc = need(o.n_pos >= 1 && o.n_dir >= 1 && (o.type == NDT_OBJ_HPLANE || o.n_size >= 1), "hplane/hdisk parameters"))) return rc;
+            b.push_vec(pos, n);
+            b.push_vec(dir, n);
+            b.push(o.type == NDT_OBJ_HDISK ? size[0] : 0.0);
+            break;
+        case NDT_OBJ_CYLINDER: {    // cylinder.c:22-40
+            if ((rc = need(o.n_pos >= 2 && o.n_size >= 1, "cylinder needs 2 pos, 1 size"))) return rc;
+            h_sub(pos + n, pos, ax, n);
+            h_unitize(ax, n);
+            b.push_vec(pos, n);
+            b.push_vec(ax, n);
+            b.push(h_dist(pos + n, pos, n));
+            b.push(h_dot(ax, ax, n));
+            b.push(h_dot(pos, ax, n));
+            b.push(size[0]);
+            if (o.n_flag > 1 && flag[1] != 0) flags |= NDT_F_INF_ENDS;     // cylinder.c:87
+            break;
+        }
+        case NDT_OBJ_HCYLINDER: {   // hcylinder.c:23-54
+            const int m = n - 2;
+            if ((rc = need(o.n_pos >= n - 1 && o.n_size >= 1, "hcylinder needs dims-1 pos, 1 size"))) return rc;
+            b.push_vec(pos, n);
+            b.push(size[0]);
+            for (int k = 0; k < m; ++k) {
+                h_sub(pos + (k + 1) * n, pos, ax, n);
+                h_unitize(ax, n);
+                b.push_vec(ax, n);
+                b.push(h_dist(pos + (k + 1) * n, pos, n));
+                b.push(h_dot(ax, ax, n));
+                b.push(h_dot(pos, ax, n));
+            }
+            aux1 = m;
+            if (o.n_flag != 0 && flag[0] != 0) flags |= NDT_F_INF_ENDS;    // hcylinder.c:107
+            break;
+        }
+        case NDT_OBJ_ORTHOTOPE: {   // orthotope.c:23-54
+            if ((rc = need(o.n_flag >= 1 && o.n_pos >= 1, "orthotope needs 1 pos, 1 flag"))) return rc;
+            const int m = flag[0];
+            if ((rc = need(m >= 0 && m <= o.n_dir && m <= n, "orthotope flag[0] vs directions"))) return rc;
+            b.push_vec(pos, n);
+            b.push(0.0);
+            for (int k = 0; k < m; ++k) {
+                memcpy(ax, dir + k * n, n * sizeof(double));
+                h_unitize(ax, n);
+                b.push_vec(ax, n);
+                b.push(h_len(dir + k * n, n));
+                b.push(h_dot(ax, ax, n));       // BdB
+                b.push(h_dot(pos, ax, n));      // BdP
+            }
+            aux1 = m;
+            break;
+        }
+        case NDT_OBJ_HCUBE:
+            aux0 = child_first[i];
+            aux1 = o.n_obj;
+            b.push(0.0);
+            break;
+        case NDT_OBJ_HFACET: {      // hfacet.c:43-87 + the ray-invariant dots of get_barycentric (hfacet.c:176-181)
+            if ((rc = need(o.n_pos >= 3 && o.n_flag >= 1, "hfacet needs 3 pos, 1 flag"))) return rc;
+            if ((rc = need(!flag[0] || o.n_dir >= 3, "hfacet with vertex normals needs 3 dir"))) return rc;
+            double edge[3][NDT_MAX_DIMS], uedge0[NDT_MAX_DIMS], perp[NDT_MAX_DIMS];
+            for (int k = 0; k < 3; ++k) h_sub(pos + ((k + 1) % 3) * n, pos + k * n, edge[k], n);
+            memcpy(uedge0, edge[0], n * sizeof(double));
+            h_unitize(uedge0, n);
+            h_scale(edge[2], -1.0, edge[2], n);
+            // vectNd_proj(edge2, edge0), vectNd.h:355
+            double bb = h_dot(edge[0], edge[0], n);
+            double ab = h_dot(edge[2], edge[0], n);
+            h_scale(edge[0], ab / bb, tmp, n);
+            h_sub(edge[2], tmp, perp, n);
+            h_unitize(perp, n);
+            b.push_vec(pos, n);
+            b.push_vec(uedge0, n);
+            b.push_vec(perp, n);
+            b.push(h_dot(uedge0, edge[0], n));  // x2
+            b.push(h_dot(perp, edge[0], n));    // y2
+            b.push(h_dot(uedge0, edge[2], n));  // x3
+            b.push(h_dot(perp, edge[2], n));    // y3
+            for (int k = 0; k < 3; ++k) {
+                if (flag[0]) b.push_vec(dir + k * n, n);
+                else { double z[NDT_MAX_DIMS] = { 0 }; b.push_vec(z, n); }
+            }
+            if (flag[0]) flags |= NDT_F_USE_NORMALS;
+            break;
+        }
+        case NDT_OBJ_FACET: {       // facet.c:42-83
+            if ((rc = need(o.n_pos >= 3 && o.n_dir >= 1, "facet needs 3 pos, 1 dir"))) return rc;
+            double edge0[NDT_MAX_DIMS], edge1[NDT_MAX_DIMS], b0[NDT_MAX_DIMS], b1[NDT_MAX_DIMS], angle[3];
+            for (int k = 0; k < 3; ++k)
+                angle[k] = h_angle3(pos + ((k + 2) % 3) * n, pos + k * n, pos + ((k + 1) % 3) * n, n);
+            h_sub(pos + n, pos, edge0, n);
+            h_sub(pos + 2 * n, pos + n, edge1, n);
+            // vectNd_orthogonalize(edge0, edge1, basis0, basis1), vectNd.c:35
+            double bb = h_dot(edge1, edge1, n);
+            double ab = h_dot(edge0, edge1, n);
+            h_scale(edge1, ab / bb, tmp, n);
+            h_sub(edge0, tmp, b0, n);
+            memcpy(b1, edge1, n * sizeof(double));
+            h_unitize(b0, n);
+            h_unitize(b1, n);
+            b.push_vec(pos, n);
+            b.push_vec(pos + n, n);
+            b.push_vec(pos + 2 * n, n);
+            b.push_vec(b0, n);
+            b.push_vec(b1, n);
+            b.push(h_dot(b0, b0, n));               // AdA, facet.c:191
+            b.push(h_dot(b1, b1, n));
+            b.push(h_dot(pos + n, b0, n));          // BdA, facet.c:200
+            b.push(h_dot(pos + n, b1, n));
+            b.push(angle[0]);
+            b.push(angle[1]);
+            b.push(angle[2]);
+            b.push_vec(dir, n);
+            break;
+        }
+        }
+        b.set_ints(sd.off_hdr + 2 * i, flags, p);
+        b.set_ints(sd.off_hdr + 2 * i + 1, aux0, aux1);
+    }
+    sd.trace_words = b.words();
+
+    // ---- shading data: materials, lights, camera
+    sd.off_mat = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        b.push(o.red); b.push(o.green); b.push(o.blue);
+        b.push(o.red_r); b.push(o.green_r); b.push(o.blue_r);
+        b.push(o.refract_index);
+        b.push(o.transparent ? 1.0 : 0.0);
+    }
+    sd.off_lights = b.words();
+    int n_shadow_lights = 0;
+    for (int i = 0; i < fs->n_lights; ++i) {
+        const ndt_flat_light &l = fs->lights[i];
+        double zero[NDT_MAX_DIMS] = { 0 };
+        if (l.type == NDT_LIGHT_DISK || l.type == NDT_LIGHT_RECT)
+            return fail(NDT_E_UNSUPPORTED, "light %d: area lights sample drand48 per ray (ndt.c:116-147); not on the device path", i);
+        if (l.type < 0 || l.type > NDT_LIGHT_RECT) return fail(NDT_E_INVALID, "light %d: type %d", i, l.type);
+        const bool want_pos = l.type == NDT_LIGHT_POINT || l.type == NDT_LIGHT_SPOT;
+        const bool want_dir = l.type == NDT_LIGHT_DIRECTIONAL || l.type == NDT_LIGHT_SPOT;
+        if (want_pos && !vec_ok(fs, l.pos_off, 1)) return fail(NDT_E_INVALID, "light %d: position missing", i);
+        if (want_dir && !vec_ok(fs, l.dir_off, 1)) return fail(NDT_E_INVALID, "light %d: direction missing", i);
+        if (l.type != NDT_LIGHT_AMBIENT) ++n_shadow_lights;
+        b.push_ints(l.type, 0);
+        b.push(l.red); b.push(l.green); b.push(l.blue);
+        b.push(l.angle);
+        b.push_vec(want_pos ? fs->vecs + l.pos_off : zero, n);
+        b.push_vec(want_dir ? fs->vecs + l.dir_off : zero, n);
+    }
+    if (!vec_ok(fs, fs->cam_pos_off, 1) || !vec_ok(fs, fs->cam_img_orig_off, 1) || !vec_ok(fs, fs->cam_dir_x_off, 1) ||
+        !vec_ok(fs, fs->cam_dir_y_off, 1))
+        return fail(NDT_E_INVALID, "camera vectors out of range");
+    sd.off_cam = b.push_vec(fs->vecs + fs->cam_pos_off, n);
+    b.push_vec(fs->vecs + fs->cam_img_orig_off, n);
+    b.push_vec(fs->vecs + fs->cam_dir_x_off, n);
+    b.push_vec(fs->vecs + fs->cam_dir_y_off, n);
+    b.push(fs->cam_focal_distance);
+    for (int i = 0; i < 3; ++i) b.push(fs->ambient[i]);
+    for (int i = 0; i < 4; ++i) b.push(fs->background[i]);
+    sd.total_words = b.words();
+
+    ctx->sd = sd;
+    ctx->blob.swap(b.w);
+    ctx->n_shadow_lights = n_shadow_lights;
+    // tier 0: trace sections fit the LDS budget and the visit mask fits registers
+    const bool fits_lds = (size_t)sd.trace_words * sizeof(double) <= NDT_TRACE_LDS_LIMIT;
+    ctx->tier = (fits_lds && sd.mask_words <= NDT_MASK_REG_WORDS) ? 0 : 1;
+    return NDT_OK;
+}
+
+extern "C" int ndt_hip_upload_scene(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
+{
+    if (!ctx || !fs) return fail(NDT_E_INVALID, "NULL argument");
+    if (fs->abi_version != NDT_HIP_ABI_VERSION) return fail(NDT_E_INVALID, "scene ABI %d, library ABI %d", fs->abi_version, NDT_HIP_ABI_VERSION);
+    if (fs->dims < NDT_MIN_DIMS || fs->dims > NDT_MAX_DIMS)
+        return fail(NDT_E_UNSUPPORTED, "%d dimensions: kernels are built for %d..%d", fs->dims, NDT_MIN_DIMS, NDT_MAX_DIMS);
+    if (fs->cam_type != 0) return fail(NDT_E_UNSUPPORTED, "camera type %d: only CAMERA_NORMAL (camera.c:557) is on the device path", fs->cam_type);
+    if (fs->n_lights < 0 || fs->n_lights > NDT_MAX_LIGHTS) return fail(NDT_E_UNSUPPORTED, "%d lights (max %d)", fs->n_lights, NDT_MAX_LIGHTS);
+    if (fs->n_objects < 0 || fs->n_items < 0 || fs->n_items > fs->n_objects) return fail(NDT_E_INVALID, "object counts");
+    if (fs->n_kd_nodes < 0 || fs->n_inf < 0 || fs->n_leaf_refs < 0) return fail(NDT_E_INVALID, "kd-tree counts");
+    if (fs->n_objects > 0 && !fs->objects) return fail(NDT_E_INVALID, "objects is NULL");
+    if (fs->n_lights > 0 && !fs->lights) return fail(NDT_E_INVALID, "lights is NULL");
+    if (!fs->vecs) return fail(NDT_E_INVALID, "vecs is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->have_scene = false;
+    int rc = build_blob(ctx, fs);
+    if (rc) return rc;
+    ctx->dims = fs->dims;
+    ctx->kt = table_for(fs->dims);
+    if (!ctx->kt) return fail(NDT_E_UNSUPPORTED, "no kernels for %d dimensions", fs->dims);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_blob_words < ctx->blob.size()) {
+        if (ctx->d_blob) HIP_TRY(hipFree(ctx->d_blob));
+        ctx->d_blob = nullptr;
+        HIP_TRY(hipMalloc((void **)&ctx->d_blob, ctx->blob.size() * sizeof(double)));
+        ctx->d_blob_words = ctx->blob.size();
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_blob, ctx->blob.data(), ctx->blob.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = true;
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+
+template <typename T> static int ws_alloc(ndt_hip_ctx *ctx, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
+    ctx->ws_allocs.push_back(q);
+    *p = (T *)q;
+    return NDT_OK;
+}
+
+static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
+{
+    Workspace &ws = ctx->ws;
+    const bool need_slab = ctx->tier == 1;
+    const long long slab_lanes = 2048LL * NDT_TRACE_BLOCK;
+    const long long slab_words = need_slab ? slab_lanes * ctx->sd.mask_words : 0;
+    if (ws.cap >= cap && ws.sh_cap >= sh_cap && ctx->ws_dims == ctx->dims && ctx->ws_slab_words >= slab_words) return NDT_OK;
+    if (cap < ws.cap) cap = ws.cap;
+    if (sh_cap < ws.sh_cap) sh_cap = ws.sh_cap;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_workspace(ctx);
+    const int n = ctx->dims;
+    int rc;
+    ws.cap = cap;
+    ws.sh_cap = sh_cap;
+    if ((rc = ws_alloc(ctx, &ws.ray_o, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_p, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_n, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.clr, (size_t)3 * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.child_refl, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.child_refr, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sh_base, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sh_mask, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.count, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.so, (size_t)n * sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sv, (size_t)n * sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.slim, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.counters, 16))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ref_rays, 2))) return rc;
+    ws.mask_slab_lanes = slab_lanes;
+    if (need_slab) {
+        if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return rc;
+    }
+    ctx->ws_slab_words = slab_words;
+    ctx->ws_dims = ctx->dims;
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ dimension-independent kernels
+
+// Bottom-up combine of one bounce: get_ray_color's blend of its own colour with the colours
+// its reflection / refraction children returned (ndt.c:402-429), in the reference's order.
+__global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc sd, Workspace ws, int specular, long long begin,
+                                                 long long count)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const long long g = begin + r;
+    if (ws.depth_left[g] <= 0) return;
+    const int obj = ws.hit_obj[g];
+    if (obj < 0) return;                        // background node: colour and count already final
+    const int mw = sd.off_mat + 8 * obj;
+    const double hitr[3] = { blob[mw + 3], blob[mw + 4], blob[mw + 5] };
+    double c[3] = { ws.clr[0 * ws.cap + g], ws.clr[1 * ws.cap + g], ws.clr[2 * ws.cap + g] };
+    int cnt = ws.count[g];
+    const int refl = ws.child_refl[g];
+    if (refl != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refl >= 0) {
+            ref[0] = ws.clr[0 * ws.cap + refl]; ref[1] = ws.clr[1 * ws.cap + refl]; ref[2] = ws.clr[2 * ws.cap + refl];
+            cnt += ws.count[refl];
+        }
+        for (int k = 0; k < 3; ++k) {
+            if (specular) c[k] = (1 - hitr[k]) * (c[k]) + (hitr[k]) * ref[k];     // ndt.c:405-407
+            else c[k] += hitr[k] * ref[k];                                         // ndt.c:411-413
+        }
+    }
+    const int refr = ws.child_refr[g];
+    if (refr != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refr >= 0) {
+            ref[0] = ws.clr[0 * ws.cap + refr]; ref[1] = ws.clr[1 * ws.cap + refr]; ref[2] = ws.clr[2 * ws.cap + refr];
+            cnt += ws.count[refr];
+        }
+        for (int k = 0; k < 3; ++k) c[k] += (1.0 - hitr[k]) * ref[k];              // ndt.c:426-428
+    }
+    ws.clr[0 * ws.cap + g] = c[0];
+    ws.clr[1 * ws.cap + g] = c[1];
+    ws.clr[2 * ws.cap + g] = c[2];
+    ws.count[g] = cnt;
+}
+
+// get_pixel_color's adaptive loop (ndt.c:488-568) replayed on the one deterministic sample:
+// with samples == 1 the reference re-traces the identical ray k times, k decided by the
+// running-mean test below; the result is (c+...+c)/k and the k-fold ray count.
+__global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
+                                                       double *rgba)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long weighted = 0ull;
+    if (g < rg.n_primary && ws.depth_left[g] > 0) {
+        const int tile = (int)(g >> 6), lane = (int)(g & 63);
+        const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
+        const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
+        const double l[4] = { ws.clr[0 * ws.cap + g], ws.clr[1 * ws.cap + g], ws.clr[2 * ws.cap + g],
+                              ws.hit_obj[g] >= 0 ? 1.0 : blob[sd.off_cam + 4 * N_ + 7] };
+        double t[4] = { 0.0, 0.0, 0.0, 0.0 };
+        const double max_diff = 1.0 / 256.0;
+        double clr_diff = 256;
+        int samples = 0;
+        for (int i = 0; i < 1 || (i < 10000 && clr_diff > max_diff); ++i) {
+            if (i > 1) {
+                const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+                const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+                const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+                const double gb = (dg > db) ? dg : db;      // MAX, image.h:31
+                clr_diff = (dr > gb) ? dr : gb;
+            }
+            t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
+            samples += 1;
+        }
+        double *out = rgba + ((long long)py * rg.width + px) * 4;   // dbl_image_set_pixel, image.c:126
+        out[0] = t[0] / samples;
+        out[1] = t[1] / samples;
+        out[2] = t[2] / samples;
+        out[3] = t[3] / samples;
+        weighted = (unsigned long long)samples * (unsigned long long)ws.count[g];
+    }
+    // one atomic per wavefront
+    for (int d = 32; d > 0; d >>= 1) weighted += __shfl_down(weighted, d, 64);
+    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays, weighted);
+}
+
+// max_optic_depth <= 0: get_ray_color returns black without tracing (ndt.c:340)
+__global__ void k_fill_black(double *rgba, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    rgba[4 * i + 0] = 0.0; rgba[4 * i + 1] = 0.0; rgba[4 * i + 2] = 0.0; rgba[4 * i + 3] = 1.0;
+}
+
+// pixel_d2c, image.h:36-39
+__global__ void k_quantize(const double *rgba, unsigned char *out, long long n_values)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_values) return;
+    const double d = rgba[i];
+    double m = (1.0 < d) ? 1.0 : d;
+    m = (0.0 > m) ? 0.0 : m;
+    out[i] = (unsigned char)(sqrt(m) * 255);
+}
+
+// ------------------------------------------------------------------ render
+
+static hipEvent_t get_event(ndt_hip_ctx *ctx, size_t idx)
+{
+    while (ctx->ev_pool.size() <= idx) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(ev);
+    }
+    return ctx->ev_pool[idx];
+}
+
+extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats)
+{
+    if (!ctx || !p || !d_rgba) return fail(NDT_E_INVALID, "NULL argument");
+    if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
+    if (p->samples != 1) return fail(NDT_E_UNSUPPORTED, "samples=%d: only the deterministic samples=1 path is implemented", p->samples);
+    if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    RenderGeom rg{};
+    rg.width = p->width;
+    rg.height = p->height;
+    rg.row_begin = p->row_begin;
+    rg.row_step = p->row_step;
+    rg.rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
+    rg.tiles_x = (rg.width + 7) / 8;
+    rg.tiles_y = (rg.rows + 7) / 8;
+    const long long n_primary = (long long)rg.tiles_x * rg.tiles_y * 64;
+    if (n_primary > 0x3fffffffLL) return fail(NDT_E_UNSUPPORTED, "image too large for one call");
+    rg.n_primary = (int)n_primary;
+    rg.max_depth = p->max_optic_depth;
+    rg.specular = p->specular ? 1 : 0;
+    ndt_render_stats st{};
+    if (rg.rows == 0) {
+        if (stats) *stats = st;
+        return NDT_OK;
+    }
+    const long long n_pixels = (long long)rg.rows * rg.width;
+    if (p->max_optic_depth <= 0) {
+        hipLaunchKernelGGL(k_fill_black, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, (double *)d_rgba, n_pixels);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        if (stats) *stats = st;
+        return NDT_OK;
+    }
+
+    long long cap = ctx->ws.cap, sh_cap = ctx->ws.sh_cap;
+    if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
+    const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
+    if (sh_cap < want_sh) sh_cap = want_sh;
+
+    const NdtKernelTable *kt = ctx->kt;
+    const bool prof = p->profile != 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
+        int rc = ensure_workspace(ctx, cap, sh_cap);
+        if (rc) return rc;
+        Workspace ws = ctx->ws;
+        size_t ev_n = 0;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+        if (prof) {
+            ev_begin = get_event(ctx, ev_n++);
+            ev_end = get_event(ctx, ev_n++);
+            HIP_TRY(hipEventRecord(ev_begin, s));
+        }
+        int *hc = ctx->h_counters;
+        hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
+        HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 2 * sizeof(unsigned long long), s));
+        kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+
+        std::vector<LevelRange> levels;
+        LevelRange lr{ 0, rg.n_primary };
+        long long shadow_total = 0;
+        int overflow = 0;
+        int launches = 0;
+        while (lr.count > 0) {
+            levels.push_back(lr);
+            // closest-hit queries of this bounce
+            TraceJob tj{};
+            tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = nullptr; tj.valid = ws.depth_left; tj.count_ptr = nullptr;
+            tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = lr.begin; tj.count = lr.count;
+            if (prof) {
+                hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
+                HIP_TRY(hipEventRecord(a, s));
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
+                HIP_TRY(hipEventRecord(b2, s));
+                trace_ev.push_back({ a, b2 });
+            } else {
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
+            }
+            ++launches;
+            HIP_TRY(hipMemsetAsync(ws.counters + 1, 0, sizeof(int), s));
+            kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, lr);
+            // shadow queries: the count lives on the device, the launch is sized for the worst case
+            if (ctx->n_shadow_lights > 0) {
+                TraceJob sj{};
+                sj.o = ws.so; sj.v = ws.sv; sj.stride = ws.sh_cap; sj.lim = ws.slim; sj.valid = nullptr;
+                sj.count_ptr = ws.counters + 1;
+                sj.out_obj = ws.sobj; sj.out_prim = ws.sprim; sj.begin = 0;
+                sj.count = lr.count * ctx->n_shadow_lights;
+                if (sj.count > ws.sh_cap) sj.count = ws.sh_cap;
+                if (prof) {
+                    hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
+                    HIP_TRY(hipEventRecord(a, s));
+                    kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
+                    HIP_TRY(hipEventRecord(b2, s));
+                    trace_ev.push_back({ a, b2 });
+                } else {
+                    kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
+                }
+                ++launches;
+            }
+            kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, lr);
+            HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipGetLastError());
+            if (hc[2] != 0) { overflow = hc[2]; break; }
+            shadow_total += hc[1];
+            const long long next_begin = lr.begin + lr.count;
+            lr.begin = next_begin;
+            lr.count = (long long)hc[0] - next_begin;
+        }
+        if (overflow) {
+            if (overflow & 1) cap *= 2;
+            if (overflow & 2) sh_cap *= 2;
+            continue;
+        }
+        // bottom-up colour resolve, deepest bounce first (the primaries last)
+        for (size_t li = levels.size(); li-- > 0;) {
+            const LevelRange &L = levels[li];
+            hipLaunchKernelGGL(k_resolve, dim3((unsigned)((L.count + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                               rg.specular, L.begin, L.count);
+        }
+        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                           rg, ctx->dims, (double *)d_rgba);
+        unsigned long long ref_rays = 0;
+        HIP_TRY(hipMemcpyAsync(hc + 8, ws.ref_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if (prof) HIP_TRY(hipEventRecord(ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
+        memcpy(&ref_rays, hc + 8, sizeof(ref_rays));
+        st.rays_primary = n_pixels;
+        st.rays_secondary = (long long)hc[0] - rg.n_primary;
+        st.rays_shadow = shadow_total;
+        st.rays_ref_equiv = (long long)ref_rays;
+        st.levels = (int)levels.size();
+        st.trace_launches = launches;
+        st.node_capacity = ws.cap;
+        if (prof) {
+            float ms = 0;
+            for (auto &pr : trace_ev) {
+                float m = 0;
+                HIP_TRY(hipEventElapsedTime(&m, pr.first, pr.second));
+                ms += m;
+            }
+            st.trace_ms = ms;
+            float fm = 0;
+            HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
+            st.frame_ms = fm;
+        }
+        if (stats) *stats = st;
+        return NDT_OK;
+    }
+    return fail(NDT_E_NOMEM, "ray-tree workspace kept overflowing");
+}
+
+extern "C" int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, ndt_render_stats *stats)
+{
+    if (!ctx || !p || !rgba) return fail(NDT_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
+    const size_t bytes = (size_t)rows * (size_t)(p->width > 0 ? p->width : 0) * 4 * sizeof(double);
+    if (bytes == 0) return ndt_hip_render_device(ctx, p, (void *)rgba, stats);
+    if (ctx->d_out_bytes < bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_out) HIP_TRY(hipFree(ctx->d_out));
+        ctx->d_out = nullptr;
+        HIP_TRY(hipMalloc(&ctx->d_out, bytes));
+        ctx->d_out_bytes = bytes;
+    }
+    int rc = ndt_hip_render_device(ctx, p, ctx->d_out, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba, ctx->d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NDT_OK;
+}
+
+extern "C" int ndt_hip_quantize_device(ndt_hip_ctx *ctx, const void *d_rgba, void *d_rgba8, int64_t n_pixels)
+{
+    if (!ctx || !d_rgba || !d_rgba8 || n_pixels < 0) return fail(NDT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long long n = n_pixels * 4;
+    if (n == 0) return NDT_OK;
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)d_rgba,
+                       (unsigned char *)d_rgba8, n);
+    HIP_TRY(hipGetLastError());
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ trace_kd batches
+
+extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double *o, const double *v, const double *dist_limit,
+                                  int32_t *obj, double *hit, double *normal)
+{
+    if (!ctx || n_rays < 0 || (n_rays > 0 && (!o || !v || !dist_limit || !obj || !hit || !normal)))
+        return fail(NDT_E_INVALID, "bad argument");
+    if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
+    if (n_rays == 0) return NDT_OK;
+    if (n_rays > 0x3fffffffLL) return fail(NDT_E_UNSUPPORTED, "too many rays for one call");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->dims;
+    const long long cnt = n_rays;
+    int rc = ensure_workspace(ctx, cnt > ctx->ws.cap ? cnt : ctx->ws.cap, ctx->ws.sh_cap > 0 ? ctx->ws.sh_cap : 4096);
+    if (rc) return rc;
+    Workspace ws = ctx->ws;
+    hipStream_t s = ctx->stream;
+    // ray-major host arrays -> component-major device batch
+    std::vector<double> so((size_t)n * cnt), sv((size_t)n * cnt);
+    for (long long r = 0; r < cnt; ++r)
+        for (int c = 0; c < n; ++c) {
+            so[(size_t)c * cnt + r] = o[r * n + c];
+            sv[(size_t)c * cnt + r] = v[r * n + c];
+        }
+    for (int c = 0; c < n; ++c) {
+        HIP_TRY(hipMemcpyAsync(ws.ray_o + (size_t)c * ws.cap, so.data() + (size_t)c * cnt, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ws.ray_v + (size_t)c * ws.cap, sv.data() + (size_t)c * cnt, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemcpyAsync(ws.frac, dist_limit, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+    TraceJob tj{};
+    tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = ws.frac; tj.valid = nullptr; tj.count_ptr = nullptr;
+    tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt;
+    ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
+    ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(obj, ws.hit_obj, cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+    for (int c = 0; c < n; ++c) {
+        HIP_TRY(hipMemcpyAsync(so.data() + (size_t)c * cnt, ws.hit_p + (size_t)c * ws.cap, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(sv.data() + (size_t)c * cnt, ws.hit_n + (size_t)c * ws.cap, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (long long r = 0; r < cnt; ++r)
+        for (int c = 0; c < n; ++c) {
+            hit[r * n + c] = so[(size_t)c * cnt + r];
+            normal[r * n + c] = sv[(size_t)c * cnt + r];
+        }
+    return NDT_OK;
+}

@@ -1,0 +1,527 @@
+// ndt_kernels.hip -- the gfx950 kernels of the wavefront tracer, compiled once per dimension
+// (-DNDT_DIMS=3..8).  One thread per ray; rays of one bounce form a structure-of-arrays batch;
+// live rays of the next bounce and the shadow rays of this one are compacted with a
+// wavefront prefix sum and one atomic per wavefront.
+//
+// Kernels per bounce (host loop in ndt_host.hip):
+//   k_trace        trace_kd (object.c:683) for every node of the bounce       -> (object, primitive)
+//   k_shade_emit   first half of apply_lights (ndt.c:71-259): hit point, same-side test,
+//                  spot cone, one shadow ray per light that passes            -> shadow queue
+//   k_trace        trace_kd for the shadow queue (dist_limit per ray)
+//   k_shade_finish second half of apply_lights (ndt.c:217-310) + the reflect / refract spawn
+//                  of get_ray_color (ndt.c:381-430)                           -> next bounce
+#include "ndt_kernels.hpp"
+
+#ifndef NDT_DIMS
+#error "compile with -DNDT_DIMS=<3..8>"
+#endif
+#define NDT_CAT2(a, b) a##b
+#define NDT_CAT(a, b) NDT_CAT2(a, b)
+
+// every dimension gets its own namespace: the six translation units define the same kernels
+namespace NDT_CAT(ndt_d, NDT_DIMS) {
+
+static constexpr int N = NDT_DIMS;
+
+// ------------------------------------------------------------------ wavefront helpers
+
+// Exclusive prefix sum of x over the 64 lanes of the wavefront; `total` = sum over all lanes.
+// Every lane of the wavefront must call it.
+NDT_DEV int wave_excl_scan(int x, int &total)
+{
+    const int lane = __lane_id();
+    int s = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(s, d, 64);
+        if (lane >= d) s += y;
+    }
+    total = __shfl(s, 63, 64);
+    return s - x;
+}
+
+// Reserve `total` consecutive slots for the wavefront with one atomic; returns the base.
+NDT_DEV int wave_reserve(int *counter, int total)
+{
+    int base = 0;
+    if (__lane_id() == 0 && total > 0) base = atomicAdd(counter, total);
+    return __shfl(base, 0, 64);
+}
+
+template <int K> NDT_DEV void load_soa(const double *base, long long stride, long long g, double (&r)[K])
+{
+#pragma unroll
+    for (int c = 0; c < K; ++c) r[c] = base[(long long)c * stride + g];
+}
+template <int K> NDT_DEV void store_soa(double *base, long long stride, long long g, const double (&r)[K])
+{
+#pragma unroll
+    for (int c = 0; c < K; ++c) base[(long long)c * stride + g] = r[c];
+}
+
+// ------------------------------------------------------------------ primary rays
+
+// render_pixel (ndt.c:578-653, MONO) + the ray set-up of get_pixel_color (ndt.c:516-549) +
+// camera_target_point's CAMERA_NORMAL branch (camera.c:557-575).
+// Slot g of the pool <-> lane (g % 64) of 8x8 pixel tile (g / 64): one wavefront = one tile.
+__global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rg.n_primary) return;
+    const int tile = (int)(g >> 6), lane = (int)(g & 63);
+    const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
+    const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
+    ws.child_refl[g] = -1;
+    ws.child_refr[g] = -1;
+    ws.count[g] = 0;
+    ws.sh_mask[g] = 0ull;
+    if (px >= rg.width || py >= rg.rows) {
+        ws.depth_left[g] = 0;       // padding slot: never traced, never shaded
+        ws.hit_obj[g] = -1;
+        return;
+    }
+    const int j = rg.row_begin + py * rg.row_step;
+    const double x = px / (double)rg.width - 0.5;               // ndt.c:632
+    const double y = -(j / (double)rg.height - 0.5);            // ndt.c:633
+    double pos[N], orig[N], dx[N], dy[N], pixel[N], temp[N], look[N];
+    blob_vec<N>(blob, sd.off_cam, pos);
+    blob_vec<N>(blob, sd.off_cam + N, orig);
+    blob_vec<N>(blob, sd.off_cam + 2 * N, dx);
+    blob_vec<N>(blob, sd.off_cam + 3 * N, dy);
+    const double focal = blob[sd.off_cam + 4 * N];
+    v_scale<N>(dx, rg.width / (double)rg.height, dx);           // ndt.c:926
+    v_copy<N>(pixel, orig);
+    v_scale<N>(dx, x, temp);
+    v_add<N>(pixel, temp, pixel);
+    v_scale<N>(dy, y, temp);
+    v_add<N>(pixel, temp, pixel);
+    const double screen_dist = v_dist<N>(orig, pos);
+    if (screen_dist > NDT_EPS) {
+        v_sub<N>(pixel, pos, temp);
+        v_scale<N>(temp, focal / screen_dist, temp);
+        v_add<N>(pos, temp, pixel);
+    }
+    v_sub<N>(pixel, pos, look);
+    v_unitize<N>(look);
+    store_soa<N>(ws.ray_o, ws.cap, g, pos);
+    store_soa<N>(ws.ray_v, ws.cap, g, look);
+    ws.frac[g] = 1.0;
+    ws.depth_left[g] = rg.max_depth;
+}
+
+// ------------------------------------------------------------------ trace
+
+// One trace_kd query per lane.  LDS tier: the trace sections of the scene blob (kd nodes, leaf
+// lists, object headers, bounding spheres, parameters) are staged once per workgroup and the
+// workgroup then walks a grid-stride range of rays, so staging is amortised over many rays.
+template <int MW, bool LDS>
+__global__ void __launch_bounds__(NDT_TRACE_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
+{
+    extern __shared__ double lds_blob[];
+    const double *blob = gblob;
+    if (LDS) {
+        for (int i = threadIdx.x; i < sd.trace_words; i += NDT_TRACE_BLOCK) lds_blob[i] = gblob[i];
+        __syncthreads();
+        blob = lds_blob;
+    }
+    VisitMask<MW> mask;
+    mask.ext = nullptr;
+    mask.ext_stride = 0;
+    if (MW == 0) {
+        const long long lane_slot = (long long)blockIdx.x * NDT_TRACE_BLOCK + threadIdx.x;
+        mask.ext = ws.mask_slab + lane_slot;
+        mask.ext_stride = (int)ws.mask_slab_lanes;
+    }
+    long long count = job.count;
+    if (job.count_ptr) {
+        const long long dyn = *job.count_ptr;      // produced by the preceding kernel on this stream
+        if (dyn < count) count = dyn;
+    }
+    const long long step = (long long)gridDim.x * NDT_TRACE_BLOCK;
+    for (long long r = (long long)blockIdx.x * NDT_TRACE_BLOCK + threadIdx.x; r < count; r += step) {
+        const long long g = job.begin + r;
+        if (job.valid && job.valid[g] <= 0) continue;
+        double o[N], v[N];
+        load_soa<N>(job.o, job.stride, g, o);
+        load_soa<N>(job.v, job.stride, g, v);
+        const double lim = job.lim ? job.lim[g] : -1.0;
+        int obj, prim;
+        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
+        job.out_obj[g] = obj;
+        job.out_prim[g] = prim;
+    }
+}
+
+static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, TraceJob job, int tier,
+                         int mask_words)
+{
+    if (job.count <= 0) return;
+    long long blocks = (job.count + NDT_TRACE_BLOCK - 1) / NDT_TRACE_BLOCK;
+    if (tier == 0) {
+        // persistent-ish: at most 8 workgroups per CU's worth of blocks, grid-stride over the rest
+        if (blocks > 2048) blocks = 2048;
+        const size_t lds = (size_t)sd.trace_words * sizeof(double);
+        if (mask_words <= 1)
+            hipLaunchKernelGGL((k_trace<1, true>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), lds, s, blob, sd, ws, job);
+        else
+            hipLaunchKernelGGL((k_trace<NDT_MASK_REG_WORDS, true>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), lds, s,
+                               blob, sd, ws, job);
+    } else {
+        const long long max_blocks = ws.mask_slab_lanes / NDT_TRACE_BLOCK;
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL((k_trace<0, false>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), 0, s, blob, sd, ws, job);
+    }
+}
+
+// ------------------------------------------------------------------ shading, first half
+
+struct LightRec {
+    int type;
+    double red, green, blue, angle;
+};
+NDT_DEV int light_word(const SceneDesc &sd, int i) { return sd.off_lights + i * (5 + 2 * N); }
+
+// Per light: everything apply_lights does before its trace_kd call (ndt.c:113-208, 230-236).
+// Returns false when the light is skipped for this hit (ambient, wrong side, outside the cone).
+struct ShadowSetup {
+    double ldist2, dist_limit;
+};
+NDT_DEV bool light_setup(const double *blob, const SceneDesc &sd, int li, const double (&src)[N], const double (&hit)[N],
+                         const double (&hit_normal)[N], int &type, double (&lgt_pos)[N], double (&rev_light)[N],
+                         double (&light_vec)[N], double (&shadow_o)[N], ShadowSetup &ss)
+{
+    const int w = light_word(sd, li);
+    type = blob_int(blob, w, 0);
+    if (type != NDT_LIGHT_POINT_ && type != NDT_LIGHT_DIRECTIONAL_ && type != NDT_LIGHT_SPOT_) return false;
+    double ldir[N], rev_view[N];
+    blob_vec<N>(blob, w + 5, lgt_pos);
+    blob_vec<N>(blob, w + 5 + N, ldir);
+    if (type == NDT_LIGHT_DIRECTIONAL_)
+        v_scale<N>(ldir, -1, rev_light);                    // ndt.c:157
+    else
+        v_sub<N>(lgt_pos, hit, rev_light);                  // ndt.c:155
+    v_unitize<N>(rev_light);
+    v_sub<N>(src, hit, rev_view);
+    const double dotRev1 = v_dot<N>(rev_light, hit_normal);
+    const double dotRev2 = v_dot<N>(rev_view, hit_normal);
+    if ((dotRev1 * dotRev2) <= 0) return false;             // ndt.c:164
+    if (type == NDT_LIGHT_DIRECTIONAL_) {
+        ss.dist_limit = 0.0;
+        ss.ldist2 = 1.0;
+        double near_pos[N];
+        v_copy<N>(near_pos, ldir);                          // ndt.c:232-235
+        v_unitize<N>(near_pos);
+        v_scale<N>(near_pos, -NDT_EPS, near_pos);
+        v_add<N>(near_pos, hit, near_pos);
+        v_copy<N>(shadow_o, near_pos);
+        v_copy<N>(light_vec, ldir);                         // what light_vec holds after a miss, ndt.c:252
+    } else {
+        ss.dist_limit = v_dist<N>(hit, lgt_pos);            // ndt.c:187-188
+        ss.dist_limit += NDT_EPS;
+        v_sub<N>(hit, lgt_pos, light_vec);                  // ndt.c:194-197
+        ss.ldist2 = v_dot<N>(light_vec, light_vec);
+        v_unitize<N>(light_vec);
+        if (type == NDT_LIGHT_SPOT_) {
+            const double angle = v_angle<N>(ldir, light_vec);
+            if ((angle * 180.0 / NDT_PI) > blob[w + 4]) return false;     // ndt.c:204
+        }
+        v_copy<N>(shadow_o, lgt_pos);
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg,
+                                                    LevelRange lr)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = r < lr.count;
+    const long long g = lr.begin + (in_range ? r : 0);
+    bool shaded = false;
+    double src[N], look[N], hit[N], nrm[N];
+    int obj = -1;
+    if (in_range && ws.depth_left[g] > 0) {
+        obj = ws.hit_obj[g];
+        if (obj >= 0) {
+            load_soa<N>(ws.ray_o, ws.cap, g, src);
+            load_soa<N>(ws.ray_v, ws.cap, g, look);
+            // the hit point and normal trace_kd would have returned: re-run the one primitive
+            // that won the traversal (same arithmetic, same result)
+            isect<N, true>(blob, sd, ws.hit_prim[g], src, look, hit, nrm);
+            const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
+            shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
+            if (shaded) {
+                store_soa<N>(ws.hit_p, ws.cap, g, hit);
+                store_soa<N>(ws.hit_n, ws.cap, g, nrm);
+            } else {
+                ws.hit_obj[g] = -1;
+            }
+        }
+        if (!shaded) {
+            // background (ndt.c:436-442); alpha is applied per pixel at the end
+            ws.clr[0 * ws.cap + g] = blob[sd.off_cam + 4 * N + 4];
+            ws.clr[1 * ws.cap + g] = blob[sd.off_cam + 4 * N + 5];
+            ws.clr[2 * ws.cap + g] = blob[sd.off_cam + 4 * N + 6];
+            ws.count[g] = 1;
+        }
+    }
+    // which lights fire a shadow ray
+    unsigned long long fire = 0ull;
+    int n_fire = 0;
+    if (shaded) {
+        for (int li = 0; li < sd.n_lights; ++li) {
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+            ShadowSetup ss;
+            if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss)) {
+                fire |= 1ull << li;
+                ++n_fire;
+            }
+        }
+    }
+    int total;
+    const int rank = wave_excl_scan(n_fire, total);
+    int base = wave_reserve(&ws.counters[1], total);
+    if (total > 0 && (long long)base + total > ws.sh_cap) {
+        if (__lane_id() == 0) atomicOr(&ws.counters[2], 2);
+        fire = 0ull;
+    }
+    if (shaded) {
+        ws.sh_base[g] = base + rank;
+        ws.sh_mask[g] = fire;
+        int slot = base + rank;
+        for (int li = 0; li < sd.n_lights; ++li) {
+            if (!((fire >> li) & 1ull)) continue;
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+            ShadowSetup ss;
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            store_soa<N>(ws.so, ws.sh_cap, slot, so);
+            // point/spot: from the light along light_vec (ndt.c:211); directional: from the
+            // nudged hit point along rev_light (ndt.c:238)
+            if (type == NDT_LIGHT_DIRECTIONAL_)
+                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
+            else
+                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
+            ws.slim[slot] = ss.dist_limit;
+            ++slot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shading, second half
+
+__global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg,
+                                                      LevelRange lr)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = r < lr.count;
+    const long long g = lr.begin + (in_range ? r : 0);
+    int obj = -1;
+    if (in_range && ws.depth_left[g] > 0) obj = ws.hit_obj[g];
+    const bool shaded = obj >= 0;
+
+    int n_child = 0;
+    bool want_refl = false, want_refr = false;
+    double refl_ray[N], refr_ray[N], hit[N];
+    double refl_frac = 0, refr_frac = 0;
+    int depth_next = 0;
+    if (shaded) {
+        double src[N], look[N], nrm[N];
+        load_soa<N>(ws.ray_o, ws.cap, g, src);
+        load_soa<N>(ws.ray_v, ws.cap, g, look);
+        load_soa<N>(ws.hit_p, ws.cap, g, hit);
+        load_soa<N>(ws.hit_n, ws.cap, g, nrm);
+        const int mw = sd.off_mat + 8 * obj;
+        const double hit_r = blob[mw], hit_g = blob[mw + 1], hit_b = blob[mw + 2];
+        const double refl_r = blob[mw + 3], refl_g = blob[mw + 4], refl_b = blob[mw + 5];
+        const bool transparent = blob[mw + 7] != 0.0;
+        double hitr_r = 0.0, hitr_g = 0.0, hitr_b = 0.0;
+        if (rg.specular) {
+            hitr_r = refl_r; hitr_g = refl_g; hitr_b = refl_b;
+        }
+        // apply_lights, ndt.c:88-92: scn->ambient first
+        double cr = hit_r * blob[sd.off_cam + 4 * N + 1];
+        double cg = hit_g * blob[sd.off_cam + 4 * N + 2];
+        double cb = hit_b * blob[sd.off_cam + 4 * N + 3];
+        const unsigned long long fire = ws.sh_mask[g];
+        int slot = ws.sh_base[g];
+        int n_shadow = 0;
+        for (int li = 0; li < sd.n_lights; ++li) {
+            const int w = light_word(sd, li);
+            const int ltype = blob_int(blob, w, 0);
+            const double lr_ = blob[w + 1], lg_ = blob[w + 2], lb_ = blob[w + 3];
+            if (ltype == NDT_LIGHT_AMBIENT_) {              // ndt.c:106-111
+                cr += hit_r * lr_;
+                cg += hit_g * lg_;
+                cb += hit_b * lb_;
+                continue;
+            }
+            if (!((fire >> li) & 1ull)) continue;
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N], light_hit_normal[N];
+            ShadowSetup ss;
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            const int sobj = ws.sobj[slot];
+            const int sprim = ws.sprim[slot];
+            ++slot;
+            ++n_shadow;
+            if (type == NDT_LIGHT_DIRECTIONAL_) {
+                if (sobj >= 0) continue;                    // anything at all shadows it, ndt.c:246
+                v_copy<N>(light_hit_normal, nrm);           // ndt.c:252-254
+            } else {
+                if (sobj != obj) continue;                  // ndt.c:217
+                double light_hit[N];
+                isect<N, true>(blob, sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                const double dist = v_dist<N>(hit, light_hit);
+                if (dist > NDT_EPS) continue;               // ndt.c:225
+            }
+            double angle = v_angle<N>(nrm, light_vec);      // ndt.c:263
+            if (angle > NDT_PI / 2.0) angle = NDT_PI - angle;
+            const double light_scale = cos(angle) / ss.ldist2;
+            if (!transparent) {
+                cr += hit_r * lr_ * light_scale;
+                cg += hit_g * lg_ * light_scale;
+                cb += hit_b * lb_ * light_scale;
+            }
+            if (rg.specular) {                              // ndt.c:276-310
+                double light_ref[N], rev_look[N];
+                v_reflect<N>(light_vec, light_hit_normal, light_ref, 0.5);
+                v_unitize<N>(light_ref);
+                v_scale<N>(look, -1, rev_look);
+                v_unitize<N>(rev_look);
+                double rv = v_dot<N>(light_ref, rev_look);
+                rv = (0 > rv) ? 0 : rv;                     // MAX(0,rv), image.h:31
+                const double rvn = pow(rv, 50.0);
+                const double gb = (lg_ > lb_) ? lg_ : lb_;
+                const double max_light = (lr_ > gb) ? lr_ : gb;
+                cr += hitr_r * lr_ / max_light * rvn;
+                cg += hitr_g * lg_ / max_light * rvn;
+                cb += hitr_b * lb_ / max_light * rvn;
+            }
+        }
+        ws.clr[0 * ws.cap + g] = cr;
+        ws.clr[1 * ws.cap + g] = cg;
+        ws.clr[2 * ws.cap + g] = cb;
+        ws.count[g] = 1 + n_shadow;
+
+        // get_ray_color, ndt.c:381-430: spawn reflection / refraction
+        const double frac = ws.frac[g];
+        depth_next = ws.depth_left[g] - 1;
+        const double gb2 = (refl_g > refl_b) ? refl_g : refl_b;
+        const double contrib = (refl_r > gb2) ? refl_r : gb2;
+        int c_refl = -1, c_refr = -1;
+        if (contrib > 0 && (refl_r != 0.0 || refl_g != 0.0 || refl_b != 0.0)) {
+            refl_frac = contrib * frac;
+            // child cut-offs (ndt.c:336-341) return black without tracing
+            if (refl_frac < (1.0 / 512.0) || depth_next <= 0) {
+                c_refl = -2;
+            } else {
+                v_reflect<N>(look, nrm, refl_ray, 1.0);
+                v_unitize<N>(refl_ray);
+                want_refl = true;
+            }
+        }
+        if (transparent) {
+            refr_frac = (1 - contrib) * frac;
+            if (refr_frac < (1.0 / 512.0) || depth_next <= 0) {
+                c_refr = -2;
+            } else {
+                v_refract<N>(look, nrm, refr_ray, blob[mw + 6]);
+                v_unitize<N>(refr_ray);
+                want_refr = true;
+            }
+        }
+        ws.child_refl[g] = c_refl;
+        ws.child_refr[g] = c_refr;
+        n_child = (want_refl ? 1 : 0) + (want_refr ? 1 : 0);
+    }
+    int total;
+    const int rank = wave_excl_scan(n_child, total);
+    const int base = wave_reserve(&ws.counters[0], total);
+    if (total > 0 && (long long)base + total > ws.cap) {
+        if (__lane_id() == 0) atomicOr(&ws.counters[2], 1);
+        return;
+    }
+    if (n_child > 0) {
+        long long c = (long long)base + rank;
+        if (want_refl) {
+            store_soa<N>(ws.ray_o, ws.cap, c, hit);
+            store_soa<N>(ws.ray_v, ws.cap, c, refl_ray);
+            ws.frac[c] = refl_frac;
+            ws.depth_left[c] = depth_next;
+            ws.child_refl[c] = -1;
+            ws.child_refr[c] = -1;
+            ws.count[c] = 0;
+            ws.sh_mask[c] = 0ull;
+            ws.child_refl[g] = (int)c;
+            ++c;
+        }
+        if (want_refr) {
+            store_soa<N>(ws.ray_o, ws.cap, c, hit);
+            store_soa<N>(ws.ray_v, ws.cap, c, refr_ray);
+            ws.frac[c] = refr_frac;
+            ws.depth_left[c] = depth_next;
+            ws.child_refl[c] = -1;
+            ws.child_refr[c] = -1;
+            ws.count[c] = 0;
+            ws.sh_mask[c] = 0ull;
+            ws.child_refr[g] = (int)c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hit points for the trace_kd batch API
+
+__global__ void __launch_bounds__(256) k_hitpoints(const double *blob, SceneDesc sd, const double *o, const double *v,
+                                                   long long stride, const int *prim, double *hit, double *nrm,
+                                                   long long count)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    double ro[N], rv[N], h[N], n[N];
+    v_zero<N>(h);
+    v_zero<N>(n);
+    const int p = prim[g];
+    if (p >= 0) {
+        load_soa<N>(o, stride, g, ro);
+        load_soa<N>(v, stride, g, rv);
+        isect<N, true>(blob, sd, p, ro, rv, h, n);
+    }
+    store_soa<N>(hit, stride, g, h);
+    store_soa<N>(nrm, stride, g, n);
+}
+
+// ------------------------------------------------------------------ launchers
+
+static unsigned grid_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+static void launch_primary(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg)
+{
+    hipLaunchKernelGGL(k_primary, dim3(grid_for(rg.n_primary, 256)), dim3(256), 0, s, blob, sd, ws, rg);
+}
+static void launch_shade_emit(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, LevelRange lr)
+{
+    if (lr.count <= 0) return;
+    hipLaunchKernelGGL(k_shade_emit, dim3(grid_for(lr.count, 256)), dim3(256), 0, s, blob, sd, ws, rg, lr);
+}
+static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, LevelRange lr)
+{
+    if (lr.count <= 0) return;
+    hipLaunchKernelGGL(k_shade_finish, dim3(grid_for(lr.count, 256)), dim3(256), 0, s, blob, sd, ws, rg, lr);
+}
+static void launch_hitpoints(hipStream_t s, const double *blob, SceneDesc sd, const double *o, const double *v,
+                             long long stride, const int *prim, double *hit, double *nrm, long long count)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_hitpoints, dim3(grid_for(count, 256)), dim3(256), 0, s, blob, sd, o, v, stride, prim, hit, nrm, count);
+}
+
+} // namespace
+
+extern "C" const NdtKernelTable *NDT_CAT(ndt_kernel_table_, NDT_DIMS)()
+{
+    using namespace NDT_CAT(ndt_d, NDT_DIMS);
+    static const NdtKernelTable table = { NDT_DIMS, launch_primary, launch_trace, launch_shade_emit, launch_shade_finish,
+                                          launch_hitpoints };
+    return &table;
+}

@@ -1,0 +1,81 @@
+// ndt_kernels.hpp -- launch interface between the host driver (ndt_host.hip) and the
+// per-dimension kernel translation units (ndt_kernels.hip compiled once per N).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ndt_device.hpp"
+
+// Device workspace of one render call.  Ray-tree nodes of all bounces live in one pool
+// (structure of arrays, component-major: x[c*cap + g]) so that lane g and lane g+1 touch
+// adjacent doubles -- one coalesced 512-byte request per component per wavefront.
+struct Workspace {
+    // node pool
+    long long cap;              // nodes the pool holds
+    double *ray_o, *ray_v;      // [N][cap]   origin / unit direction
+    double *frac;               // [cap]      pixel_frac (ndt.c:330)
+    int *depth_left;            // [cap]      max_depth of this node; 0 = padding slot
+    int *hit_obj, *hit_prim;    // [cap]      trace_kd result: material owner / primitive; <0 = miss
+    double *hit_p, *hit_n;      // [N][cap]   hit point / normal (apply_lights inputs)
+    double *clr;                // [3][cap]   local colour, then resolved colour
+    int *child_refl, *child_refr; // [cap]    -1 none, -2 cut-off (black), >=0 node
+    int *sh_base;               // [cap]      first shadow-queue slot of this node
+    unsigned long long *sh_mask;// [cap]      lights that fired a shadow ray
+    int *count;                 // [cap]      trace_kd calls in this node's subtree
+    // shadow queue of the current bounce
+    long long sh_cap;
+    double *so, *sv;            // [N][sh_cap]
+    double *slim;               // [sh_cap]   dist_limit
+    int *sobj, *sprim;          // [sh_cap]
+    // counters: [0] node tail, [1] shadow tail, [2] overflow flags (1 nodes, 2 shadows)
+    int *counters;
+    unsigned long long *ref_rays;   // [1] rays the reference would have traced (k-weighted)
+    unsigned long long *mask_slab;  // visit masks for scenes too big for registers
+    long long mask_slab_lanes;
+};
+
+struct RenderGeom {
+    int width, height;          // full image
+    int row_begin, row_step;    // shard
+    int rows;                   // rows of this shard
+    int tiles_x, tiles_y;       // 8x8 tiles over (width, rows)
+    int n_primary;              // tiles_x*tiles_y*64 (padding slots included)
+    int max_depth;
+    int specular;
+};
+
+struct TraceJob {
+    const double *o, *v;        // [N][stride]
+    long long stride;
+    const double *lim;          // per-ray dist_limit, or nullptr => -1 (closest hit)
+    const int *valid;           // depth_left, or nullptr => all valid
+    const int *count_ptr;       // device-side ray count (<= count), or nullptr
+    int *out_obj, *out_prim;
+    long long begin, count;
+};
+
+struct LevelRange {
+    long long begin, count;     // nodes of the bounce being processed
+};
+
+// One table per compiled dimension.
+struct NdtKernelTable {
+    int dims;
+    void (*primary)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom);
+    // tier: 0 = scene staged in LDS, visit mask in registers; 1 = scene in global memory, mask in the slab
+    void (*trace)(hipStream_t, const double *blob, SceneDesc, Workspace, TraceJob, int tier, int mask_words);
+    void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, LevelRange);
+    void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, LevelRange);
+    void (*hitpoints)(hipStream_t, const double *blob, SceneDesc, const double *o, const double *v, long long stride,
+                      const int *prim, double *hit, double *nrm, long long count);
+};
+
+extern "C" const NdtKernelTable *ndt_kernel_table_3();
+extern "C" const NdtKernelTable *ndt_kernel_table_4();
+extern "C" const NdtKernelTable *ndt_kernel_table_5();
+extern "C" const NdtKernelTable *ndt_kernel_table_6();
+extern "C" const NdtKernelTable *ndt_kernel_table_7();
+extern "C" const NdtKernelTable *ndt_kernel_table_8();
+
+#define NDT_TRACE_BLOCK 256
+#define NDT_TRACE_LDS_LIMIT (64 * 1024)     /* bytes of scene staged per workgroup: two workgroups per CU */
+#define NDT_MASK_REG_WORDS 4                /* 64-bit words of visit mask kept in registers (256 items) */

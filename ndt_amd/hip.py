@@ -1,0 +1,140 @@
+"""ctypes binding of libndt_hip.so (include/ndt_hip.h) -- the product's only compute path.
+
+There is deliberately no fallback: if the shared library is missing or no MI355X is present,
+construction raises.  The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .flat_scene import RenderParams, RenderStats, shard_rows
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndt_hip.so")
+
+# every entry point include/ndt_hip.h declares
+API_SYMBOLS = [
+    "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
+    "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
+    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version",
+]
+
+
+class NdtHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libndt_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libndt_hip.so (built in-tree by __graft_entry__.build() / ndt_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `make -C ndt_amd/csrc` (or __graft_entry__.build()). "
+            "ndt_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 +
+    # libhsa-runtime64.so, and a process that loads /opt/rocm's copy first and torch's second
+    # ends up with two HSA runtimes ("No HIP GPUs are available").  Importing torch first makes
+    # the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.ndt_hip_last_error.restype = C.c_char_p
+    lib.ndt_hip_stream.restype = C.c_void_p
+    lib.ndt_hip_stream.argtypes = [C.c_void_p]
+    lib.ndt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.ndt_hip_destroy.argtypes = [C.c_void_p]
+    lib.ndt_hip_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_trace_rays.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+    lib.ndt_hip_quantize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.ndt_hip_synchronize.argtypes = [C.c_void_p]
+    lib.ndt_hip_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    _lib = lib
+    return lib
+
+
+class NdtHip:
+    """One rendering context = one MI355X + one HIP stream (ndt_hip_create)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        self._check(self.lib.ndt_hip_create(int(device), C.byref(self.ctx)))
+        self.device = int(device)
+        self.scene = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NdtHipError(rc, (self.lib.ndt_hip_last_error() or b"").decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.ndt_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self.lib.ndt_hip_stream(self.ctx)
+
+    def synchronize(self):
+        self._check(self.lib.ndt_hip_synchronize(self.ctx))
+
+    def upload_scene(self, fs):
+        self._check(self.lib.ndt_hip_upload_scene(self.ctx, fs.byref()))
+        self.scene = fs          # keep the arrays alive; also gives dims
+
+    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
+        return RenderParams(width, height, depth, 1, row_begin, row_step, specular, profile)
+
+    def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
+        """render_image for a row shard; returns ((rows, width, 4) float64 host array, RenderStats)."""
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile)
+        rows = shard_rows(height, row_begin, row_step)
+        out = np.zeros((rows, width, 4), dtype=np.float64)
+        st = RenderStats()
+        self._check(self.lib.ndt_hip_render(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st
+
+    def render_device(self, d_rgba_ptr, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
+        """Same, output left in HBM at raw device pointer `d_rgba_ptr` (rows*width*4 doubles)."""
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile)
+        st = RenderStats()
+        self._check(self.lib.ndt_hip_render_device(self.ctx, C.byref(p), C.c_void_p(d_rgba_ptr), C.byref(st)))
+        return st
+
+    def quantize_device(self, d_rgba_ptr, d_rgba8_ptr, n_pixels):
+        self._check(self.lib.ndt_hip_quantize_device(self.ctx, C.c_void_p(d_rgba_ptr), C.c_void_p(d_rgba8_ptr),
+                                                     int(n_pixels)))
+
+    def trace_rays(self, rays):
+        """Batch of trace_kd queries; rays: (n, 2*dims+1) = o, v, dist_limit per row."""
+        d = self.scene.dims
+        n = rays.shape[0]
+        o = np.ascontiguousarray(rays[:, :d], dtype=np.float64)
+        v = np.ascontiguousarray(rays[:, d:2 * d], dtype=np.float64)
+        lim = np.ascontiguousarray(rays[:, 2 * d], dtype=np.float64)
+        obj = np.zeros(n, dtype=np.int32)
+        hit = np.zeros((n, d))
+        nrm = np.zeros((n, d))
+        self._check(self.lib.ndt_hip_trace_rays(self.ctx, n, o.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                                lim.ctypes.data_as(C.c_void_p), obj.ctypes.data_as(C.c_void_p),
+                                                hit.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)))
+        return obj, hit, nrm
