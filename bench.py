@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the ndt ray-trace hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one render_image call (reference ndt.c:900) of the workload frame.
+
+Workload (N=1): BASELINE.json configs[2] -- scenes/random.c, 4-D, 1920x1080, `-l 4`, full
+object-plugin set + kd-tree -- the configuration the north_star's target is quoted on.  The
+scene is the committed fixture tests/golden/c3_random4d.ndtscene.gz (flattened from the
+compiled reference), i.e. synthetic data.
+N>1: the same scene and camera; the frame grows to N x (1920x1080) pixels at the same aspect
+ratio (N=4 is exactly configs[3]'s 3840x2160), rows are dealt cyclically to the ranks like the
+reference's MPI_ROW mode (ndt.c:812-820) and one RCCL gather over xGMI assembles the double
+image on rank 0 -- per-GPU work is fixed, so "scaling": "weak".
+
+`value` counts rays ACTUALLY traced on the GPUs (one trace_kd query each).  The reference
+re-traces every pixel's identical ray tree k = 3..18 times (adaptive loop, ndt.c:488; SURVEY
+8a row A3); the GPU path traces it once and replays the loop's arithmetic, so the
+reference-equivalent rate (what the CPU baseline's rays/time means) is reported separately as
+`mray_s_ref_equiv`, never as `value`.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before libndt_hip: one HIP runtime per process, see ndt_amd/hip.py)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (fixture, depth, reference scene .so, dims, BASELINE config index)
+    "random4d": ("c3_random4d", 4, "random", 4, 2),
+    "balls4d": ("c2_balls4d", 128, "balls", 4, 1),
+    "hypercube3d": ("c1_hypercube3d", 128, "hypercube", 3, 0),
+}
+
+
+def frame_size(n_gpus):
+    """N x 1080p pixels at 16:9, multiples of 8 (N=1: 1920x1080, N=4: 3840x2160)."""
+    s = math.sqrt(n_gpus)
+    w = int(round(1920 * s / 8.0)) * 8
+    h = int(round(1080 * s / 8.0)) * 8
+    return w, h
+
+
+def algorithmic_bytes_per_ray(dims):
+    """ray record w+r, hit record w+r, framebuffer RMW = 64N + 168 bytes."""
+    return 64 * dims + 168
+
+
+def cpu_baseline(workload, width, height, depth):
+    """Time the reference itself (oracle/_ref, built from /root/reference by oracle/Makefile) on
+    the host cores of this box, for the same frame.  Falls back to the oracle port if the
+    reference build did not travel."""
+    fixture, _, scene_so, dims, _ = WORKLOADS[workload]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    shim = os.path.join(ROOT, "oracle", "_ref", "ndt_ref_shim")
+    if os.path.exists(shim):
+        cmd = [shim, "--objects", os.path.join(ROOT, "oracle", "_ref", "objects"),
+               "--scene", os.path.join(ROOT, "oracle", "_ref", "scenes", scene_so + ".so"),
+               "--dims", str(dims), "--res", "%dx%d" % (width, height), "--threads", str(cores),
+               "--depth", str(depth), "--tmp", "/tmp"]
+        try:
+            out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout
+            sec = float(re.search(r"ref_shim: render_s ([0-9.]+)", out).group(1))
+            rays = int(re.search(r"rays_total (\d+)", out).group(1))
+            return {"value": rays / sec / 1e6, "unit": "Mray/s", "cores": cores, "kind": "reference",
+                    "sample": "%s %d-D %dx%d -l %d, whole frame once, reference render_image with %d pthreads "
+                              "(%.2f s, %d trace_kd calls)" % (scene_so, dims, width, height, depth, cores, sec, rays),
+                    "frame_s": sec, "rays": rays}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write("cpu_baseline: reference run failed (%s); timing the oracle port\n" % e)
+    from ndt_amd import load_scene, RenderParams, RenderStats
+    so = os.path.join(ROOT, "oracle", "libndt_oracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    fs = load_scene(os.path.join(ROOT, "tests", "golden", fixture + ".ndtscene.gz"))
+    # literal re-sampling (flags=1): the port then does the reference's full work, k samples per pixel
+    sh = max(8, height // 4)
+    p = RenderParams(width, height, depth, 1, 0, max(1, height // sh), 1, 0)
+    st = RenderStats()
+    rows = (height + p.row_step - 1) // p.row_step
+    buf = np.zeros((rows, width, 4))
+    t0 = time.time()
+    lib.ndt_oracle_render(fs.byref(), C.byref(p), buf.ctypes.data_as(C.c_void_p), C.byref(st), C.c_int(cores), C.c_int(1))
+    sec = time.time() - t0
+    return {"value": st.rays_ref_equiv / sec / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": "%s %dx%d -l %d, every %d-th row, oracle port with literal re-sampling, %d threads" % (
+                fixture, width, height, depth, p.row_step, cores),
+            "frame_s": sec * p.row_step, "rays": int(st.rays_ref_equiv)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="random4d", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="f64", choices=["f64", "rgba8"], help="what the image gather moves")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libndt_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ndt_amd import load_scene, shard_rows
+    from ndt_amd.hip import NdtHip
+
+    fixture, depth, _, dims, cfg_idx = WORKLOADS[args.workload]
+    fs = load_scene(os.path.join(ROOT, "tests", "golden", fixture + ".ndtscene.gz"))
+    width, height = frame_size(world)
+    gpu = NdtHip(local_rank)
+    gpu.upload_scene(fs)
+
+    rows_local = shard_rows(height, rank, world)
+    rows_max = shard_rows(height, 0, world)
+    local = torch.zeros((rows_max, width, 4), dtype=torch.float64, device="cuda")
+    local8 = torch.zeros((rows_max, width, 4), dtype=torch.uint8, device="cuda") if args.gather == "rgba8" else None
+    gathered = None
+    image = None
+    if world > 1 and rank == 0:
+        src = local8 if local8 is not None else local
+        gathered = [torch.empty_like(src) for _ in range(world)]
+        image = torch.empty((height, width, 4), dtype=src.dtype, device="cuda")
+
+    def step(profile):
+        st = gpu.render_device(local.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
+        if world > 1:
+            src = local
+            if local8 is not None:
+                gpu.quantize_device(local.data_ptr(), local8.data_ptr(), rows_max * width)
+                gpu.synchronize()
+                src = local8
+            dist.gather(src, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    n = shard_rows(height, r, world)
+                    image[r::world] = gathered[r][:n]
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(0)
+    fence()
+    t0 = time.perf_counter()
+    agg = {"traced": 0, "ref_equiv": 0, "trace_ms": 0.0, "launches": 0, "primary": 0, "secondary": 0, "shadow": 0,
+           "frame_ms": 0.0, "levels": 0}
+    for _ in range(args.steps):
+        st = step(1)
+        agg["traced"] += st.rays_primary + st.rays_secondary + st.rays_shadow
+        agg["primary"] += st.rays_primary
+        agg["secondary"] += st.rays_secondary
+        agg["shadow"] += st.rays_shadow
+        agg["ref_equiv"] += st.rays_ref_equiv
+        agg["trace_ms"] += st.trace_ms
+        agg["launches"] += st.trace_launches
+        agg["frame_ms"] += st.frame_ms
+        agg["levels"] = max(agg["levels"], st.levels)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    counts = torch.tensor([agg["traced"], agg["ref_equiv"]], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_traced, total_ref = counts.tolist()
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        bytes_per_ray = algorithmic_bytes_per_ray(dims)
+        rays_rank0 = agg["traced"]
+        avg_launch_ms = agg["trace_ms"] / max(1, agg["launches"])
+        rays_per_launch = rays_rank0 / max(1, agg["launches"])
+        achieved = (rays_per_launch * bytes_per_ray) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        line = {
+            "metric": "Mray/s (primary+shadow+reflect) at 1920x1080",
+            "value": total_traced / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[%d]: %s scene (tests/golden/%s.ndtscene.gz), %d-D, %dx%d, -l %d, "
+                            "samples=1, mono, kd-tree on, specular on; rows cyclic over %d GPU(s)%s" % (
+                                cfg_idx, args.workload, fixture, dims, width, height, depth, world,
+                                ", RCCL gather of the %s image to rank 0" % args.gather if world > 1 else ""),
+                "width": width, "height": height, "dims": dims, "max_optic_depth": depth,
+                "parallelism": "rows%d" % world,
+            },
+            "rays_traced_per_step": total_traced / steps,
+            "rays_ref_equiv_per_step": total_ref / steps,
+            "mray_s_ref_equiv": total_ref / elapsed / 1e6,
+            "ray_mix_rank0_per_step": {"primary": agg["primary"] / steps, "secondary": agg["secondary"] / steps,
+                                        "shadow": agg["shadow"] / steps, "bounces": agg["levels"]},
+            "device_frame_ms_rank0": agg["frame_ms"] / steps,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_trace (trace_kd, one ray per lane)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_ray": bytes_per_ray,
+                "rays_per_launch": rays_per_launch,
+                "avg_launch_ms": avg_launch_ms,
+                "launches_per_step": agg["launches"] / steps,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -649,111 +649,27 @@ template <int MW> struct VisitMask {
     }
 };
 
-// Result of one list scan (`trace`, object.c:692-747): the accepted object, the primitive
-// that produced the hit point (a face for an hcube, else the object itself), and min_dist.
-struct ListHit {
-    double min_dist;
-    int obj, prim;
-};
-
-// trace(), object.c:692-747, over objs = int section `sec` [first, first+cnt).
-// Nested hcube faces (hcube.c:236-250) run as an inner list with the same body, so the
-// primitive intersector is instantiated once.
-template <int N, int MW, bool USE_MASK>
-NDT_DEV ListHit trace_list(const double *blob, const SceneDesc &sd, int sec, int first, int cnt, VisitMask<MW> &mask,
-                           const double (&o)[N], const double (&v)[N], double dist_limit)
-{
-    ListHit best;
-    best.min_dist = -1;
-    best.obj = -1;
-    best.prim = -1;
-    // inner (hcube) list state
-    bool in_sub = false;
-    int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
-    double sub_min = -1;
-    int i = 0;
-    while (true) {
-        int prim = -1, owner = -1;
-        double gate_min = -1;
-        bool have_result = false, ret = false;
-        double dist = -1;
-        int hit_prim = -1;
-        if (in_sub) {
-            if (sub_i == sub_end) {
-                // nested trace finished: hcube.intersect returns its verdict (hcube.c:241-248)
-                in_sub = false;
-                have_result = true;
-                ret = (sub_min >= 0);
-                dist = sub_min;     // == |o - res| of the accepted face, same arithmetic
-                owner = sub_owner;
-                hit_prim = sub_prim;
-                prim = -1;
-            } else {
-                prim = blob_int_at(blob, sd.off_child, sub_i++);
-                owner = sub_owner;
-                gate_min = sub_min;
-            }
-        } else {
-            if (i == cnt) break;
-            const int id = blob_int_at(blob, sec, first + i);
-            ++i;
-            if (USE_MASK) {
-                if (mask.test_and_set(id)) continue;        // object.c:707-713
-            }
-            const int h = sd.off_hdr + 2 * id;
-            const int flags = blob_int(blob, h, 0);
-            if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
-                // vect_object_intersect gate on the hcube itself (object.c:618-624)
-                if ((flags & NDT_F_GATE) && !bsphere_gate<N>(blob, sd, id, o, v, best.min_dist)) continue;
-                in_sub = true;
-                sub_owner = id;
-                sub_i = blob_int(blob, h + 1, 0);
-                sub_end = sub_i + blob_int(blob, h + 1, 1);
-                sub_min = -1;
-                sub_prim = -1;
-                continue;
-            }
-            prim = id;
-            owner = id;
-            gate_min = best.min_dist;
-        }
-        if (!have_result) {
-            const int flags = blob_int(blob, sd.off_hdr + 2 * prim, 0);
-            bool ok = true;
-            if (flags & NDT_F_GATE) ok = bsphere_gate<N>(blob, sd, prim, o, v, gate_min);
-            if (ok) {
-                double res[N], nrm[N];
-                ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
-                if (ok) dist = v_dist<N>(o, res);       // object.c:721
-            }
-            if (in_sub) {
-                // inner trace(): dist_limit = -1, no mask (hcube.c:241)
-                if (ok && dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
-                    sub_min = dist;
-                    sub_prim = prim;
-                }
-                continue;
-            }
-            ret = ok;
-            hit_prim = prim;
-        }
-        if (ret) {
-            if (dist > NDT_EPS && (dist + NDT_EPS < best.min_dist || best.min_dist < 0)) {   // object.c:722
-                best.min_dist = dist;
-                best.obj = owner;
-                best.prim = hit_prim;
-            }
-            if (dist_limit == 0.0 || dist < dist_limit) break;                                 // object.c:730
-        }
-    }
-    return best;
-}
-
 #define NDT_KD_STACK 40
+#define NDT_STACK_FLAG 0x40000000   /* stack entry of the (unreachable) ray-parallel branch */
 
-// trace_kd (object.c:683) = kd_tree_intersect (kd-tree.c:570-625) with kd_node_intersect
-// (kd-tree.c:482-568) unrolled onto an explicit stack.  The recursion visits `near`, then
-// re-checks `*t_ptr > gate` before `far`; the stack entry carries that gate.
+// trace_kd (object.c:683) = kd_tree_intersect (kd-tree.c:570-625), with
+//   kd_node_intersect (kd-tree.c:482-568)  unrolled onto an explicit stack,
+//   trace             (object.c:692-747)   as the list scan,
+//   hcube.intersect   (hcube.c:236-250)    as a nested list scan,
+// restructured for a 64-wide wavefront as three phases that every lane runs in lock-step:
+//
+//   T  walk the tree until THIS lane stands on a list to scan (infinite list first, then
+//      leaves).  The wavefront leaves phase T when every lane has a list or is finished.
+//   G  scan forward through the list until THIS lane finds a primitive whose bounding-sphere
+//      gate passes (cheap, ~40 instructions per step).
+//   I  intersect that primitive (expensive).  All lanes that found one do it together, each
+//      on its own object.
+//
+// The results are exactly the reference's: per lane, objects are visited in list order, the
+// gate sees the running min_dist, the visit mask is set as the scan advances, and the
+// dist_limit `break` (object.c:730) ends the scan where the reference's loop would.  What
+// changes is only which lanes wait for which: a lane never sits through another lane's
+// intersection unless it has one of its own to do.
 template <int N, int MW>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim)
@@ -770,118 +686,246 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             r = 1.0 / v_i;
         v_inv[i] = r;
     }
-    // infinite objects first, linear, unmasked (kd-tree.c:594)
-    double t = NDT_DBL_MAX;
-    ListHit inf = trace_list<N, MW, false>(blob, sd, sd.off_inf, 0, sd.n_inf, mask, o, v, dist_limit);
-    const bool ret_inf = inf.min_dist >= 0;
-    if (inf.min_dist > NDT_EPS) t = inf.min_dist;       // object.c:736
-    out_obj = inf.obj;
-    out_prim = inf.prim;
 
-    // aabb_intersect on the root box, kd-tree.c:84-127
-    double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
-    bool box = true;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (box) {
-            double v_i = v[i], o_i = o[i];
-            if (!(fabs(v_i) < NDT_EPS2)) {
-                double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
-                double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
-                if (tl_i > tu_i) {
-                    double tmp = tl_i;
-                    tl_i = tu_i;
-                    tu_i = tmp;
-                }
-                if (tl_i > tl) tl = tl_i;
-                if (tu_i < tu) tu = tu_i;
-                if (tu < -NDT_EPS) box = false;
-            }
-        }
-    }
-    if (box) {
-        tl -= NDT_EPS;
-        tu += NDT_EPS;
-        box = (tu >= -NDT_EPS) && (tl <= tu);
-    }
-    if (!box || sd.n_kd_nodes <= 0) return;
-
-    mask.clear(sd.mask_words);
-    double lt = NDT_DBL_MAX;
-    int l_obj = -1, l_prim = -1;
+    // results
+    double t_inf = NDT_DBL_MAX;             // `t` of kd_tree_intersect, kd-tree.c:593
+    bool ret_inf = false;
+    int inf_obj = -1, inf_prim = -1;
+    double lt = NDT_DBL_MAX;                // `lt`, kd-tree.c:599
     bool lret = false;
+    int l_obj = -1, l_prim = -1;
 
+    // traversal state
     int st_node[NDT_KD_STACK];
-    double st_tl[NDT_KD_STACK], st_tu[NDT_KD_STACK], st_gate[NDT_KD_STACK];
+    double st_a[NDT_KD_STACK], st_tu[NDT_KD_STACK];
     int sp = 0;
     int node = 0;
-    double ntl = tl, ntu = tu;
-    bool have = true;
+    double ntl = 0, ntu = 0;
+    bool have_node = false, started = false, done = false;
+
+    // current list
+    bool have_list = false, list_is_inf = false;
+    int sec = 0, pos = 0, end = 0;
+    double min_dist = -1;                   // trace()'s min_dist for the current list
+    int best_obj = -1, best_prim = -1;
+    // nested (hcube) list
+    bool in_sub = false;
+    int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
+    double sub_min = -1;
+
+    if (sd.n_inf > 0) {
+        // infinite objects first, linear, unmasked (kd-tree.c:594)
+        have_list = true;
+        list_is_inf = true;
+        sec = sd.off_inf;
+        pos = 0;
+        end = sd.n_inf;
+    }
+
     while (true) {
-        if (!have) {
-            if (sp == 0) break;
-            --sp;
-            node = st_node[sp];
-            ntl = st_tl[sp];
-            ntu = st_tu[sp];
-            if (!(lt > st_gate[sp])) continue;      // the `*t_ptr > ...` test before the far call
-        }
-        have = false;
-        if (ntu < 0.0) continue;                    // kd-tree.c:490
-        const int k = sd.off_kd + 2 * node;
-        const int dim = blob_int(blob, k, 0);
-        if (dim < 0) {
-            // leaf: trace() over its items (kd-tree.c:497-519)
-            const int first = blob_int(blob, k + 1, 0), num = blob_int(blob, k + 1, 1);
-            if (num > 0) {
-                ListHit lh = trace_list<N, MW, true>(blob, sd, sd.off_leaf, first, num, mask, o, v, dist_limit);
-                if (lh.min_dist >= 0) {
-                    lret = true;
-                    if (lh.min_dist < lt) {         // `ret && t < *t_ptr`; t is set whenever ret (dist > EPS)
-                        lt = lh.min_dist;
-                        l_obj = lh.obj;
-                        l_prim = lh.prim;
+        // ------------------------------------------------------------ phase T
+        while (!have_list && !done) {
+            if (!started) {
+                started = true;
+                // aabb_intersect on the root box, kd-tree.c:84-127
+                double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
+                bool box = true;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    if (box) {
+                        double v_i = v[i], o_i = o[i];
+                        if (!(fabs(v_i) < NDT_EPS2)) {
+                            double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
+                            double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
+                            if (tl_i > tu_i) {
+                                double tmp = tl_i;
+                                tl_i = tu_i;
+                                tu_i = tmp;
+                            }
+                            if (tl_i > tl) tl = tl_i;
+                            if (tu_i < tu) tu = tu_i;
+                            if (tu < -NDT_EPS) box = false;
+                        }
                     }
                 }
-            }
-            continue;
-        }
-        const double boundary = blob[k + 1];
-        int near = node + 1, far = blob_int(blob, k, 1);    // preorder: left child follows its parent
-        const double v_inv_i = v_pick<N>(v_inv, dim);
-        const double o_i = v_pick<N>(o, dim);
-        if (v_inv_i < NDT_EPS2) {
-            int tmp = near;
-            near = far;
-            far = tmp;
-        }
-        if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
-            const double tp = (boundary - o_i) * v_inv_i;
-            // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before pushing
-            // the far child is safe; the test that counts is repeated at pop time, after the
-            // near subtree has been searched, exactly like the second `if` at kd-tree.c:552.
-            if (ntu < tp - NDT_EPS && lt > ntl) {
-                node = near; have = true;                       // near only, same interval
-            } else if (ntl > tp + NDT_EPS && lt > ntl) {
-                node = far; have = true;                        // far only, same interval
-            } else {
-                if (lt > tp) {
-                    st_node[sp] = far; st_tl[sp] = tp - NDT_EPS; st_tu[sp] = ntu; st_gate[sp] = tp; ++sp;
+                if (box) {
+                    tl -= NDT_EPS;
+                    tu += NDT_EPS;
+                    box = (tu >= -NDT_EPS) && (tl <= tu);
                 }
-                if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have = true; }
+                if (!box || sd.n_kd_nodes <= 0) {
+                    done = true;
+                    break;
+                }
+                mask.clear(sd.mask_words);
+                node = 0;
+                ntl = tl;
+                ntu = tu;
+                have_node = true;
             }
-        } else {
-            // plane parallel to the ray (unreachable for finite v_inv, kept for fidelity: kd-tree.c:555-565)
-            const bool go_far = o_i > boundary - NDT_EPS;
-            const bool go_near = o_i < boundary + NDT_EPS && lt > ntl;
-            if (go_far) {
-                st_node[sp] = far; st_tl[sp] = ntl; st_tu[sp] = ntu; st_gate[sp] = ntl; ++sp;
+            if (!have_node) {
+                if (sp == 0) {
+                    done = true;
+                    break;
+                }
+                --sp;
+                const int nf = st_node[sp];
+                const double a = st_a[sp];
+                ntu = st_tu[sp];
+                node = nf & ~NDT_STACK_FLAG;
+                // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
+                if (!(lt > a)) continue;
+                ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
             }
-            if (go_near) { node = near; have = true; }
+            have_node = false;
+            if (ntu < 0.0) continue;                    // kd-tree.c:490
+            const int k = sd.off_kd + 2 * node;
+            const int dim = blob_int(blob, k, 0);
+            if (dim < 0) {
+                // leaf: trace() over its items (kd-tree.c:497-519)
+                const int num = blob_int(blob, k + 1, 1);
+                if (num > 0) {
+                    have_list = true;
+                    list_is_inf = false;
+                    sec = sd.off_leaf;
+                    pos = blob_int(blob, k + 1, 0);
+                    end = pos + num;
+                }
+                continue;
+            }
+            const double boundary = blob[k + 1];
+            int near = node + 1, far = blob_int(blob, k, 1);    // preorder: left child follows its parent
+            const double v_inv_i = v_pick<N>(v_inv, dim);
+            const double o_i = v_pick<N>(o, dim);
+            if (v_inv_i < NDT_EPS2) {
+                int tmp = near;
+                near = far;
+                far = tmp;
+            }
+            if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
+                const double tp = (boundary - o_i) * v_inv_i;
+                // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before
+                // pushing the far child is safe; the test that counts is repeated at pop time.
+                if (ntu < tp - NDT_EPS && lt > ntl) {
+                    node = near; have_node = true;              // near only, same interval
+                } else if (ntl > tp + NDT_EPS && lt > ntl) {
+                    node = far; have_node = true;               // far only, same interval
+                } else {
+                    if (lt > tp) {
+                        st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
+                    }
+                    if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have_node = true; }
+                }
+            } else {
+                // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
+                // by construction), kept for fidelity with kd-tree.c:555-565
+                if (o_i > boundary - NDT_EPS) {
+                    st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
+                }
+                if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
+            }
+        }
+        if (!have_list) break;      // done
+
+        // ------------------------------------------------------------ phases G + I over the list
+        min_dist = -1;
+        best_obj = -1;
+        best_prim = -1;
+        while (true) {
+            // ---- phase G: advance to the next primitive that passes its gate
+            int prim = -1;
+            while (true) {
+                if (in_sub) {
+                    if (sub_i == sub_end) {
+                        // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
+                        // then the outer trace() applies its accept / break rules
+                        in_sub = false;
+                        if (sub_min >= 0) {
+                            const double dist = sub_min;    // == |o - res| of the accepted face
+                            if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {
+                                min_dist = dist;
+                                best_obj = sub_owner;
+                                best_prim = sub_prim;
+                            }
+                            if (dist_limit == 0.0 || dist < dist_limit) pos = end;      // break
+                        }
+                        continue;
+                    }
+                    const int p = blob_int_at(blob, sd.off_child, sub_i);
+                    ++sub_i;
+                    const int flags = blob_int(blob, sd.off_hdr + 2 * p, 0);
+                    if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, p, o, v, sub_min)) {
+                        prim = p;
+                        break;
+                    }
+                    continue;
+                }
+                if (pos == end) break;
+                const int id = blob_int_at(blob, sec, pos);
+                ++pos;
+                if (!list_is_inf) {
+                    if (mask.test_and_set(id)) continue;        // object.c:707-713
+                }
+                const int flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
+                // vect_object_intersect's gate (object.c:618-624), for composites too
+                if ((flags & NDT_F_GATE) && !bsphere_gate<N>(blob, sd, id, o, v, min_dist)) continue;
+                if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
+                    in_sub = true;
+                    sub_owner = id;
+                    sub_i = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
+                    sub_end = sub_i + blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+                    sub_min = -1;
+                    sub_prim = -1;
+                    continue;
+                }
+                prim = id;
+                break;
+            }
+            if (prim < 0) break;        // list exhausted
+
+            // ---- phase I: intersect
+            double res[N], nrm[N];
+            const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
+            if (ok) {
+                const double dist = v_dist<N>(o, res);          // object.c:721
+                if (in_sub) {
+                    // inner trace(): dist_limit = -1, no mask (hcube.c:241)
+                    if (dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
+                        sub_min = dist;
+                        sub_prim = prim;
+                    }
+                } else {
+                    if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {       // object.c:722
+                        min_dist = dist;
+                        best_obj = prim;
+                        best_prim = prim;
+                    }
+                    if (dist_limit == 0.0 || dist < dist_limit) pos = end;                      // object.c:730
+                }
+            }
+        }
+
+        // ---- list finished: what trace() returns to its caller
+        have_list = false;
+        if (list_is_inf) {
+            ret_inf = min_dist >= 0;
+            if (min_dist > NDT_EPS) t_inf = min_dist;           // object.c:736
+            inf_obj = best_obj;
+            inf_prim = best_prim;
+        } else if (min_dist >= 0) {
+            lret = true;
+            if (min_dist < lt) {                                // `ret && t < *t_ptr`, kd-tree.c:506
+                lt = min_dist;
+                l_obj = best_obj;
+                l_prim = best_prim;
+            }
         }
     }
+
+    out_obj = inf_obj;
+    out_prim = inf_prim;
     if (lret) {
-        if (!ret_inf || (lt > NDT_EPS && lt + NDT_EPS < t)) {   // kd-tree.c:612
+        if (!ret_inf || (lt > NDT_EPS && lt + NDT_EPS < t_inf)) {   // kd-tree.c:612
             out_obj = l_obj;
             out_prim = l_prim;
         }

@@ -62,6 +62,7 @@ struct ndt_hip_ctx {
     std::vector<void *> ws_allocs;
     long long ws_dims = 0;
     long long ws_slab_words = 0;
+    int ws_nseg = 0;
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
     int *h_counters = nullptr;      // pinned
@@ -103,7 +104,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
         delete ctx;
         return fail(NDT_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    e = hipHostMalloc((void **)&ctx->h_counters, 16 * sizeof(int), hipHostMallocDefault);
+    e = hipHostMalloc((void **)&ctx->h_counters, 128 * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -120,6 +121,7 @@ static void free_workspace(ndt_hip_ctx *ctx)
     memset(&ctx->ws, 0, sizeof(ctx->ws));
     ctx->ws_slab_words = 0;
     ctx->ws_dims = 0;
+    ctx->ws_nseg = 0;
 }
 
 extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
@@ -589,7 +591,9 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     const bool need_slab = ctx->tier == 1;
     const long long slab_lanes = 2048LL * NDT_TRACE_BLOCK;
     const long long slab_words = need_slab ? slab_lanes * ctx->sd.mask_words : 0;
-    if (ws.cap >= cap && ws.sh_cap >= sh_cap && ctx->ws_dims == ctx->dims && ctx->ws_slab_words >= slab_words) return NDT_OK;
+    if (ws.cap >= cap && ws.sh_cap >= sh_cap && ctx->ws_dims == ctx->dims && ctx->ws_slab_words >= slab_words &&
+        ctx->ws_nseg >= ctx->n_shadow_lights)
+        return NDT_OK;
     if (cap < ws.cap) cap = ws.cap;
     if (sh_cap < ws.sh_cap) sh_cap = ws.sh_cap;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -609,7 +613,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.clr, (size_t)3 * cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.child_refl, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.child_refr, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sh_base, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sh_idx, (size_t)cap * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1)))) return rc;
     if ((rc = ws_alloc(ctx, &ws.sh_mask, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.count, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.so, (size_t)n * sh_cap))) return rc;
@@ -617,7 +621,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.slim, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.counters, 16))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 2))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -625,6 +629,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     }
     ctx->ws_slab_words = slab_words;
     ctx->ws_dims = ctx->dims;
+    ctx->ws_nseg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
     return NDT_OK;
 }
 
@@ -803,10 +808,12 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 2 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_SLOTS * sizeof(int), s));
+        int queue_slot = 0;
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
 
         std::vector<LevelRange> levels;
-        LevelRange lr{ 0, rg.n_primary };
+        LevelRange lr{ 0, rg.n_primary, 0 };
         long long shadow_total = 0;
         int overflow = 0;
         int launches = 0;
@@ -814,8 +821,10 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             levels.push_back(lr);
             // closest-hit queries of this bounce
             TraceJob tj{};
-            tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = nullptr; tj.valid = ws.depth_left; tj.count_ptr = nullptr;
+            tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = nullptr; tj.valid = ws.depth_left; tj.n_seg = 0;
             tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = lr.begin; tj.count = lr.count;
+            if (queue_slot + 2 > NDT_QUEUE_SLOTS) return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS / 2);
+            tj.queue = ws.counters + NDT_CNT_QUEUE + queue_slot++;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                 HIP_TRY(hipEventRecord(a, s));
@@ -826,16 +835,24 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
             }
             ++launches;
-            HIP_TRY(hipMemsetAsync(ws.counters + 1, 0, sizeof(int), s));
+            // shadow queue: one segment per non-ambient light, each able to hold the whole bounce
+            const int n_seg = ctx->n_shadow_lights;
+            lr.seg_stride = (lr.count + 63) & ~63LL;
+            if ((long long)n_seg * lr.seg_stride > ws.sh_cap) {
+                overflow = 2;
+                sh_cap = (long long)n_seg * lr.seg_stride;      // doubled below
+                break;
+            }
+            levels.back() = lr;
+            HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_SEG, 0, 64 * sizeof(int), s));
             kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, lr);
-            // shadow queries: the count lives on the device, the launch is sized for the worst case
-            if (ctx->n_shadow_lights > 0) {
+            if (n_seg > 0) {
                 TraceJob sj{};
                 sj.o = ws.so; sj.v = ws.sv; sj.stride = ws.sh_cap; sj.lim = ws.slim; sj.valid = nullptr;
-                sj.count_ptr = ws.counters + 1;
+                sj.seg_count = ws.counters + NDT_CNT_SEG; sj.seg_stride = lr.seg_stride; sj.n_seg = n_seg;
                 sj.out_obj = ws.sobj; sj.out_prim = ws.sprim; sj.begin = 0;
-                sj.count = lr.count * ctx->n_shadow_lights;
-                if (sj.count > ws.sh_cap) sj.count = ws.sh_cap;
+                sj.queue = ws.counters + NDT_CNT_QUEUE + queue_slot++;
+                sj.count = lr.count * n_seg;        // upper bound, sizes the grid only
                 if (prof) {
                     hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                     HIP_TRY(hipEventRecord(a, s));
@@ -849,10 +866,11 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             }
             kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, lr);
             HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(hc + 16, ws.counters + NDT_CNT_SEG, 64 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipGetLastError());
             if (hc[2] != 0) { overflow = hc[2]; break; }
-            shadow_total += hc[1];
+            for (int k = 0; k < n_seg; ++k) shadow_total += hc[16 + k];
             const long long next_begin = lr.begin + lr.count;
             lr.begin = next_begin;
             lr.count = (long long)hc[0] - next_begin;
@@ -964,8 +982,10 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     }
     HIP_TRY(hipMemcpyAsync(ws.frac, dist_limit, cnt * sizeof(double), hipMemcpyHostToDevice, s));
     TraceJob tj{};
-    tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = ws.frac; tj.valid = nullptr; tj.count_ptr = nullptr;
+    tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = ws.frac; tj.valid = nullptr; tj.n_seg = 0;
     tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt;
+    tj.queue = ws.counters + NDT_CNT_QUEUE;
+    HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, sizeof(int), s));
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());

@@ -11,6 +11,7 @@
 //   k_shade_finish second half of apply_lights (ndt.c:217-310) + the reflect / refract spawn
 //                  of get_ray_color (ndt.c:381-430)                           -> next bounce
 #include "ndt_kernels.hpp"
+#include <stdlib.h>
 
 #ifndef NDT_DIMS
 #error "compile with -DNDT_DIMS=<3..8>"
@@ -112,15 +113,18 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 // ------------------------------------------------------------------ trace
 
 // One trace_kd query per lane.  LDS tier: the trace sections of the scene blob (kd nodes, leaf
-// lists, object headers, bounding spheres, parameters) are staged once per workgroup and the
-// workgroup then walks a grid-stride range of rays, so staging is amortised over many rays.
+// lists, object headers, bounding spheres, parameters) are staged once per workgroup; the
+// workgroups are persistent and every wavefront pulls batches of 64 rays from a device-side
+// queue (one atomic per batch), so a wavefront that drew cheap rays (sky) immediately takes
+// more work instead of idling until the expensive tiles finish.  Every wavefront exits when
+// the queue head passes the ray count.
 template <int MW, bool LDS>
-__global__ void __launch_bounds__(NDT_TRACE_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
+__global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
     extern __shared__ double lds_blob[];
     const double *blob = gblob;
     if (LDS) {
-        for (int i = threadIdx.x; i < sd.trace_words; i += NDT_TRACE_BLOCK) lds_blob[i] = gblob[i];
+        for (int i = threadIdx.x; i < sd.trace_words; i += blockDim.x) lds_blob[i] = gblob[i];
         __syncthreads();
         blob = lds_blob;
     }
@@ -128,19 +132,43 @@ __global__ void __launch_bounds__(NDT_TRACE_BLOCK) k_trace(const double *gblob, 
     mask.ext = nullptr;
     mask.ext_stride = 0;
     if (MW == 0) {
-        const long long lane_slot = (long long)blockIdx.x * NDT_TRACE_BLOCK + threadIdx.x;
+        const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         mask.ext = ws.mask_slab + lane_slot;
         mask.ext_stride = (int)ws.mask_slab_lanes;
     }
-    long long count = job.count;
-    if (job.count_ptr) {
-        const long long dyn = *job.count_ptr;      // produced by the preceding kernel on this stream
-        if (dyn < count) count = dyn;
+    const int lane = __lane_id();
+    // batches of 64 rays; for a segmented queue every segment is padded to whole batches
+    long long n_batches;
+    int seg_batches_incl = 0, seg_cnt = 0;      // lane s: inclusive prefix of batches / count of segment s
+    if (job.n_seg > 0) {
+        seg_cnt = (lane < job.n_seg) ? job.seg_count[lane] : 0;
+        int total;
+        const int excl = wave_excl_scan((seg_cnt + 63) >> 6, total);
+        seg_batches_incl = excl + ((seg_cnt + 63) >> 6);
+        n_batches = total;
+    } else {
+        n_batches = (job.count + 63) >> 6;
     }
-    const long long step = (long long)gridDim.x * NDT_TRACE_BLOCK;
-    for (long long r = (long long)blockIdx.x * NDT_TRACE_BLOCK + threadIdx.x; r < count; r += step) {
-        const long long g = job.begin + r;
-        if (job.valid && job.valid[g] <= 0) continue;
+    while (true) {
+        int b = 0;
+        if (lane == 0) b = atomicAdd(job.queue, 1);
+        b = __shfl(b, 0, 64);
+        if (b >= n_batches) break;
+        long long g;
+        if (job.n_seg > 0) {
+            // segment of batch b = number of segments whose inclusive prefix is <= b
+            const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= b));
+            const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
+            const int cnt = __shfl(seg_cnt, s, 64);
+            const int idx = (b - first) * 64 + lane;
+            if (idx >= cnt) continue;
+            g = (long long)s * job.seg_stride + idx;
+        } else {
+            const long long r = (long long)b * 64 + lane;
+            if (r >= job.count) continue;
+            g = job.begin + r;
+            if (job.valid && job.valid[g] <= 0) continue;
+        }
         double o[N], v[N];
         load_soa<N>(job.o, job.stride, g, o);
         load_soa<N>(job.v, job.stride, g, v);
@@ -152,24 +180,50 @@ __global__ void __launch_bounds__(NDT_TRACE_BLOCK) k_trace(const double *gblob, 
     }
 }
 
+static int env_int(const char *name, int def)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : def;
+}
+
+template <typename K> static int resident_blocks(K kernel, int block, size_t lds)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return per_cu * cus;
+}
+
 static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, TraceJob job, int tier,
                          int mask_words)
 {
     if (job.count <= 0) return;
-    long long blocks = (job.count + NDT_TRACE_BLOCK - 1) / NDT_TRACE_BLOCK;
+    static const int block = env_int("NDT_TRACE_BLOCK", NDT_TRACE_BLOCK);
+    long long blocks = (job.count + block - 1) / block;
     if (tier == 0) {
-        // persistent-ish: at most 8 workgroups per CU's worth of blocks, grid-stride over the rest
-        if (blocks > 2048) blocks = 2048;
         const size_t lds = (size_t)sd.trace_words * sizeof(double);
-        if (mask_words <= 1)
-            hipLaunchKernelGGL((k_trace<1, true>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), lds, s, blob, sd, ws, job);
-        else
-            hipLaunchKernelGGL((k_trace<NDT_MASK_REG_WORDS, true>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), lds, s,
-                               blob, sd, ws, job);
+        if (mask_words <= 1) {
+            static int res = 0;
+            if (!res) res = resident_blocks(k_trace<1, true>, block, lds);
+            if (blocks > res) blocks = res;
+            hipLaunchKernelGGL((k_trace<1, true>), dim3((unsigned)blocks), dim3(block), lds, s, blob, sd, ws, job);
+        } else {
+            static int res = 0;
+            if (!res) res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true>, block, lds);
+            if (blocks > res) blocks = res;
+            hipLaunchKernelGGL((k_trace<NDT_MASK_REG_WORDS, true>), dim3((unsigned)blocks), dim3(block), lds, s, blob, sd, ws, job);
+        }
     } else {
-        const long long max_blocks = ws.mask_slab_lanes / NDT_TRACE_BLOCK;
+        static int res = 0;
+        if (!res) res = resident_blocks(k_trace<0, false>, block, 0);
+        if (blocks > res) blocks = res;
+        const long long max_blocks = ws.mask_slab_lanes / block;
         if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL((k_trace<0, false>), dim3((unsigned)blocks), dim3(NDT_TRACE_BLOCK), 0, s, blob, sd, ws, job);
+        hipLaunchKernelGGL((k_trace<0, false>), dim3((unsigned)blocks), dim3(block), 0, s, blob, sd, ws, job);
     }
 }
 
@@ -264,48 +318,47 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
             ws.count[g] = 1;
         }
     }
-    // which lights fire a shadow ray
+    // One shadow ray per light that passes the same-side / cone tests.  The queue is segmented
+    // by light: the rays a wavefront later traces then share their origin (the light) and aim
+    // at neighbouring hit points, instead of interleaving five unrelated origins.  Within a
+    // segment live rays are compacted with a wavefront ballot + one atomic per wavefront.
     unsigned long long fire = 0ull;
-    int n_fire = 0;
-    if (shaded) {
-        for (int li = 0; li < sd.n_lights; ++li) {
-            int type;
-            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
-            ShadowSetup ss;
-            if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss)) {
+    const int lane = __lane_id();
+    int seg = 0;
+    for (int li = 0; li < sd.n_lights; ++li) {
+        const int ltype = blob_int(blob, light_word(sd, li), 0);
+        if (ltype == NDT_LIGHT_AMBIENT_) continue;          // wave-uniform
+        int type = 0;
+        double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+        ShadowSetup ss;
+        ss.dist_limit = 0;
+        ss.ldist2 = 1;
+        bool fires = false;
+        if (shaded) fires = light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+        const unsigned long long vote = __ballot(fires);
+        const int total = __popcll(vote);
+        if (total > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ws.counters[NDT_CNT_SEG + seg], total);
+            base = __shfl(base, 0, 64);
+            if (fires) {
+                const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
+                const long long slot = (long long)seg * lr.seg_stride + idx;
+                ws.sh_idx[(long long)seg * ws.cap + g] = idx;
                 fire |= 1ull << li;
-                ++n_fire;
+                store_soa<N>(ws.so, ws.sh_cap, slot, so);
+                // point/spot: from the light along light_vec (ndt.c:211); directional: from the
+                // nudged hit point along rev_light (ndt.c:238)
+                if (type == NDT_LIGHT_DIRECTIONAL_)
+                    store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
+                else
+                    store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
+                ws.slim[slot] = ss.dist_limit;
             }
         }
+        ++seg;
     }
-    int total;
-    const int rank = wave_excl_scan(n_fire, total);
-    int base = wave_reserve(&ws.counters[1], total);
-    if (total > 0 && (long long)base + total > ws.sh_cap) {
-        if (__lane_id() == 0) atomicOr(&ws.counters[2], 2);
-        fire = 0ull;
-    }
-    if (shaded) {
-        ws.sh_base[g] = base + rank;
-        ws.sh_mask[g] = fire;
-        int slot = base + rank;
-        for (int li = 0; li < sd.n_lights; ++li) {
-            if (!((fire >> li) & 1ull)) continue;
-            int type;
-            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
-            ShadowSetup ss;
-            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
-            store_soa<N>(ws.so, ws.sh_cap, slot, so);
-            // point/spot: from the light along light_vec (ndt.c:211); directional: from the
-            // nudged hit point along rev_light (ndt.c:238)
-            if (type == NDT_LIGHT_DIRECTIONAL_)
-                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
-            else
-                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
-            ws.slim[slot] = ss.dist_limit;
-            ++slot;
-        }
-    }
+    if (shaded) ws.sh_mask[g] = fire;
 }
 
 // ------------------------------------------------------------------ shading, second half
@@ -344,8 +397,8 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
         double cg = hit_g * blob[sd.off_cam + 4 * N + 2];
         double cb = hit_b * blob[sd.off_cam + 4 * N + 3];
         const unsigned long long fire = ws.sh_mask[g];
-        int slot = ws.sh_base[g];
         int n_shadow = 0;
+        int seg = -1;
         for (int li = 0; li < sd.n_lights; ++li) {
             const int w = light_word(sd, li);
             const int ltype = blob_int(blob, w, 0);
@@ -356,14 +409,15 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
                 cb += hit_b * lb_;
                 continue;
             }
+            ++seg;
             if (!((fire >> li) & 1ull)) continue;
+            const long long slot = (long long)seg * lr.seg_stride + ws.sh_idx[(long long)seg * ws.cap + g];
             int type;
             double lgt_pos[N], rev_light[N], light_vec[N], so[N], light_hit_normal[N];
             ShadowSetup ss;
             light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
             const int sobj = ws.sobj[slot];
             const int sprim = ws.sprim[slot];
-            ++slot;
             ++n_shadow;
             if (type == NDT_LIGHT_DIRECTIONAL_) {
                 if (sobj >= 0) continue;                    // anything at all shadows it, ndt.c:246

@@ -18,7 +18,7 @@ struct Workspace {
     double *hit_p, *hit_n;      // [N][cap]   hit point / normal (apply_lights inputs)
     double *clr;                // [3][cap]   local colour, then resolved colour
     int *child_refl, *child_refr; // [cap]    -1 none, -2 cut-off (black), >=0 node
-    int *sh_base;               // [cap]      first shadow-queue slot of this node
+    int *sh_idx;                // [n_seg][cap] index of this node's shadow ray inside its light's segment
     unsigned long long *sh_mask;// [cap]      lights that fired a shadow ray
     int *count;                 // [cap]      trace_kd calls in this node's subtree
     // shadow queue of the current bounce
@@ -26,7 +26,8 @@ struct Workspace {
     double *so, *sv;            // [N][sh_cap]
     double *slim;               // [sh_cap]   dist_limit
     int *sobj, *sprim;          // [sh_cap]
-    // counters: [0] node tail, [1] shadow tail, [2] overflow flags (1 nodes, 2 shadows)
+    // counters: [0] node tail, [2] overflow flags (1 nodes, 2 shadows),
+    // [NDT_CNT_QUEUE ..) work-queue heads, [NDT_CNT_SEG ..) shadow rays per light segment
     int *counters;
     unsigned long long *ref_rays;   // [1] rays the reference would have traced (k-weighted)
     unsigned long long *mask_slab;  // visit masks for scenes too big for registers
@@ -48,13 +49,20 @@ struct TraceJob {
     long long stride;
     const double *lim;          // per-ray dist_limit, or nullptr => -1 (closest hit)
     const int *valid;           // depth_left, or nullptr => all valid
-    const int *count_ptr;       // device-side ray count (<= count), or nullptr
+    // segmented queue (shadow rays, one segment per light so that a wavefront's rays share
+    // their origin): segment s holds seg_count[s] rays at [s*seg_stride, ...); n_seg == 0 => one
+    // dense range [begin, begin+count)
+    const int *seg_count;
+    long long seg_stride;
+    int n_seg;
+    int *queue;                 // device-side work-queue head for this launch (zeroed by the host)
     int *out_obj, *out_prim;
     long long begin, count;
 };
 
 struct LevelRange {
     long long begin, count;     // nodes of the bounce being processed
+    long long seg_stride;       // capacity of one light's shadow segment for this bounce (>= count)
 };
 
 // One table per compiled dimension.
@@ -77,5 +85,10 @@ extern "C" const NdtKernelTable *ndt_kernel_table_7();
 extern "C" const NdtKernelTable *ndt_kernel_table_8();
 
 #define NDT_TRACE_BLOCK 256
+#define NDT_TRACE_MAX_BLOCK 768
+#define NDT_QUEUE_SLOTS 1024                /* work-queue heads per render call */
+#define NDT_CNT_QUEUE 16
+#define NDT_CNT_SEG (NDT_CNT_QUEUE + NDT_QUEUE_SLOTS)
+#define NDT_CNT_TOTAL (NDT_CNT_SEG + 64)
 #define NDT_TRACE_LDS_LIMIT (64 * 1024)     /* bytes of scene staged per workgroup: two workgroups per CU */
 #define NDT_MASK_REG_WORDS 4                /* 64-bit words of visit mask kept in registers (256 items) */
