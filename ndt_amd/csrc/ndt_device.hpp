@@ -649,8 +649,6 @@ template <int MW> struct VisitMask {
     }
 };
 
-#define NDT_KD_STACK 40
-#define NDT_STACK_FLAG 0x40000000   /* stack entry of the (unreachable) ray-parallel branch */
 
 // trace_kd (object.c:683) = kd_tree_intersect (kd-tree.c:570-625), with
 //   kd_node_intersect (kd-tree.c:482-568)  unrolled onto an explicit stack,
@@ -670,10 +668,57 @@ template <int MW> struct VisitMask {
 // dist_limit `break` (object.c:730) ends the scan where the reference's loop would.  What
 // changes is only which lanes wait for which: a lane never sits through another lane's
 // intersection unless it has one of its own to do.
+#define NDT_KD_STACK 40
+#define NDT_STACK_FLAG 0x40000000   /* stack entry of the (unreachable) ray-parallel branch */
+
+// Traversal stack: one entry per pending far child, in a per-lane scratch array.  (A variant
+// that kept the top four entries in shifted registers measured 8 % slower on MI355X: the
+// kernel is instruction-issue bound, not scratch-latency bound; see DESIGN.md.)
+struct KdStack {
+    int s_node[NDT_KD_STACK];
+    double s_a[NDT_KD_STACK], s_tu[NDT_KD_STACK];
+    int n;
+    NDT_DEV void init() { n = 0; }
+    NDT_DEV bool empty() const { return n == 0; }
+    NDT_DEV void push(int node, double a, double tu)
+    {
+        s_node[n] = node;
+        s_a[n] = a;
+        s_tu[n] = tu;
+        ++n;
+    }
+    NDT_DEV void pop(int &node, double &a, double &tu)
+    {
+        --n;
+        node = s_node[n];
+        a = s_a[n];
+        tu = s_tu[n];
+    }
+};
+
+#ifdef NDT_PHASE_TIMING
+// diagnostic build only: wave-level cycle stamps per phase (never enabled in the shipped library)
+#define NDT_STAMP(slot)                                                   \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();     \
+        ph[slot] += now_ - ph_last;                                       \
+        ph_last = now_;                                                   \
+    } while (0)
+#else
+#define NDT_STAMP(slot) do { } while (0)
+#endif
+
 template <int N, int MW>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
-                      const double (&v)[N], double dist_limit, int &out_obj, int &out_prim)
+                      const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
+#ifdef NDT_PHASE_TIMING
+                      , unsigned long long (&ph)[4]
+#endif
+                      )
 {
+#ifdef NDT_PHASE_TIMING
+    unsigned long long ph_last = __builtin_readcyclecounter();
+#endif
     double v_inv[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -696,9 +741,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int l_obj = -1, l_prim = -1;
 
     // traversal state
-    int st_node[NDT_KD_STACK];
-    double st_a[NDT_KD_STACK], st_tu[NDT_KD_STACK];
-    int sp = 0;
+    KdStack stack;
+    stack.init();
     int node = 0;
     double ntl = 0, ntu = 0;
     bool have_node = false, started = false, done = false;
@@ -764,14 +808,13 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 have_node = true;
             }
             if (!have_node) {
-                if (sp == 0) {
+                if (stack.empty()) {
                     done = true;
                     break;
                 }
-                --sp;
-                const int nf = st_node[sp];
-                const double a = st_a[sp];
-                ntu = st_tu[sp];
+                int nf;
+                double a;
+                stack.pop(nf, a, ntu);
                 node = nf & ~NDT_STACK_FLAG;
                 // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
                 if (!(lt > a)) continue;
@@ -812,7 +855,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     node = far; have_node = true;               // far only, same interval
                 } else {
                     if (lt > tp) {
-                        st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
+                        stack.push(far, tp, ntu);       // far: (tp-EPS, tu), gate tp
                     }
                     if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have_node = true; }
                 }
@@ -820,11 +863,12 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
                 // by construction), kept for fidelity with kd-tree.c:555-565
                 if (o_i > boundary - NDT_EPS) {
-                    st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
+                    stack.push(far | NDT_STACK_FLAG, ntl, ntu);
                 }
                 if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
             }
         }
+        NDT_STAMP(0);
         if (!have_list) break;      // done
 
         // ------------------------------------------------------------ phases G + I over the list
@@ -881,6 +925,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 prim = id;
                 break;
             }
+            NDT_STAMP(1);
             if (prim < 0) break;        // list exhausted
 
             // ---- phase I: intersect
@@ -903,9 +948,11 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     if (dist_limit == 0.0 || dist < dist_limit) pos = end;                      // object.c:730
                 }
             }
+            NDT_STAMP(2);
         }
 
         // ---- list finished: what trace() returns to its caller
+        NDT_STAMP(3);
         have_list = false;
         if (list_is_inf) {
             ret_inf = min_dist >= 0;

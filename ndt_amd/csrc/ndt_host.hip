@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -623,6 +624,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 2))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.dbg, 64))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
         if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return rc;
@@ -799,6 +801,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         size_t ev_n = 0;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+        std::vector<std::string> trace_dbg;
         if (prof) {
             ev_begin = get_event(ctx, ev_n++);
             ev_end = get_event(ctx, ev_n++);
@@ -808,6 +811,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 2 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(ws.dbg, 0, 64 * sizeof(unsigned long long), s));
         HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_SLOTS * sizeof(int), s));
         int queue_slot = 0;
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
@@ -831,6 +835,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
                 HIP_TRY(hipEventRecord(b2, s));
                 trace_ev.push_back({ a, b2 });
+                trace_dbg.push_back("closest, bounce " + std::to_string(levels.size() - 1) + ", " + std::to_string(lr.count) + " nodes");
             } else {
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
             }
@@ -859,6 +864,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                     kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
                     HIP_TRY(hipEventRecord(b2, s));
                     trace_ev.push_back({ a, b2 });
+                    trace_dbg.push_back("shadow, bounce " + std::to_string(levels.size() - 1));
                 } else {
                     kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
                 }
@@ -871,6 +877,14 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             HIP_TRY(hipGetLastError());
             if (hc[2] != 0) { overflow = hc[2]; break; }
             for (int k = 0; k < n_seg; ++k) shadow_total += hc[16 + k];
+            if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
+                unsigned long long d[8];
+                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4])
+                    fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[4]);
+                long long sh = 0;
+                for (int k = 0; k < n_seg; ++k) sh += hc[16 + k];
+                fprintf(stderr, "ndt_hip: bounce %zu: %lld nodes, %lld shadow rays\n", levels.size() - 1, lr.count, sh);
+            }
             const long long next_begin = lr.begin + lr.count;
             lr.begin = next_begin;
             lr.count = (long long)hc[0] - next_begin;
@@ -909,6 +923,13 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 ms += m;
             }
             st.trace_ms = ms;
+            if (getenv("NDT_HIP_DEBUG_LEVELS")) {
+                for (size_t i = 0; i < trace_ev.size(); ++i) {
+                    float m = 0;
+                    (void)hipEventElapsedTime(&m, trace_ev[i].first, trace_ev[i].second);
+                    fprintf(stderr, "ndt_hip: trace launch %zu: %.3f ms (%s)\n", i, m, trace_dbg[i].c_str());
+                }
+            }
             float fm = 0;
             HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
             st.frame_ms = fm;

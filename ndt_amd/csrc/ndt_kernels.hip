@@ -137,17 +137,24 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         mask.ext_stride = (int)ws.mask_slab_lanes;
     }
     const int lane = __lane_id();
-    // batches of 64 rays; for a segmented queue every segment is padded to whole batches
+#ifdef NDT_PHASE_TIMING
+    unsigned long long ph[4] = { 0, 0, 0, 0 };
+#endif
+    // batches of `bs` rays (64, or fewer when the launch has too few rays to fill the chip: a
+    // wavefront's time is set by its slowest lane, so half-empty wavefronts finish sooner and
+    // there are idle CUs to run them); for a segmented queue every segment is padded to whole batches
+    const int bs = job.batch;
+    const int sh = (bs == 64) ? 6 : (bs == 32) ? 5 : (bs == 16) ? 4 : 3;
     long long n_batches;
     int seg_batches_incl = 0, seg_cnt = 0;      // lane s: inclusive prefix of batches / count of segment s
     if (job.n_seg > 0) {
         seg_cnt = (lane < job.n_seg) ? job.seg_count[lane] : 0;
         int total;
-        const int excl = wave_excl_scan((seg_cnt + 63) >> 6, total);
-        seg_batches_incl = excl + ((seg_cnt + 63) >> 6);
+        const int excl = wave_excl_scan((seg_cnt + bs - 1) >> sh, total);
+        seg_batches_incl = excl + ((seg_cnt + bs - 1) >> sh);
         n_batches = total;
     } else {
-        n_batches = (job.count + 63) >> 6;
+        n_batches = (job.count + bs - 1) >> sh;
     }
     while (true) {
         int b = 0;
@@ -160,12 +167,12 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= b));
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
             const int cnt = __shfl(seg_cnt, s, 64);
-            const int idx = (b - first) * 64 + lane;
-            if (idx >= cnt) continue;
+            const int idx = (b - first) * bs + lane;
+            if (lane >= bs || idx >= cnt) continue;
             g = (long long)s * job.seg_stride + idx;
         } else {
-            const long long r = (long long)b * 64 + lane;
-            if (r >= job.count) continue;
+            const long long r = (long long)b * bs + lane;
+            if (lane >= bs || r >= job.count) continue;
             g = job.begin + r;
             if (job.valid && job.valid[g] <= 0) continue;
         }
@@ -174,10 +181,20 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         load_soa<N>(job.v, job.stride, g, v);
         const double lim = job.lim ? job.lim[g] : -1.0;
         int obj, prim;
+#ifdef NDT_PHASE_TIMING
+        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph);
+#else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
+#endif
         job.out_obj[g] = obj;
         job.out_prim[g] = prim;
     }
+#ifdef NDT_PHASE_TIMING
+    if (lane == 0 && ws.dbg) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&ws.dbg[i], ph[i]);
+        atomicAdd(&ws.dbg[4], 1ull);
+    }
+#endif
 }
 
 static int env_int(const char *name, int def)
@@ -203,9 +220,13 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
 {
     if (job.count <= 0) return;
     static const int block = env_int("NDT_TRACE_BLOCK", NDT_TRACE_BLOCK);
-    long long blocks = (job.count + block - 1) / block;
+    static const int force_batch = env_int("NDT_TRACE_BATCH", 0);
+    job.batch = 64;
+    if (force_batch == 64 || force_batch == 32 || force_batch == 16 || force_batch == 8) job.batch = force_batch;
+    long long blocks = (job.count + job.batch * (block / 64) - 1) / (job.batch * (block / 64));
     if (tier == 0) {
-        const size_t lds = (size_t)sd.trace_words * sizeof(double);
+        static const int extra_lds = env_int("NDT_TRACE_EXTRA_LDS", 0);   // experiment knob: lowers occupancy
+        const size_t lds = (size_t)sd.trace_words * sizeof(double) + (size_t)extra_lds;
         if (mask_words <= 1) {
             static int res = 0;
             if (!res) res = resident_blocks(k_trace<1, true>, block, lds);

@@ -32,6 +32,7 @@ struct Workspace {
     unsigned long long *ref_rays;   // [1] rays the reference would have traced (k-weighted)
     unsigned long long *mask_slab;  // visit masks for scenes too big for registers
     long long mask_slab_lanes;
+    unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
 };
 
 struct RenderGeom {
@@ -56,6 +57,7 @@ struct TraceJob {
     long long seg_stride;
     int n_seg;
     int *queue;                 // device-side work-queue head for this launch (zeroed by the host)
+    int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
     int *out_obj, *out_prim;
     long long begin, count;
 };

@@ -12,7 +12,7 @@ import numpy as np
 from .flat_scene import RenderParams, RenderStats, shard_rows
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndt_hip.so")
+LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 
 # every entry point include/ndt_hip.h declares
 API_SYMBOLS = [
