@@ -36,12 +36,12 @@ enum { NDT_LIGHT_AMBIENT_ = 0, NDT_LIGHT_POINT_ = 1, NDT_LIGHT_DIRECTIONAL_ = 2,
 struct SceneDesc {
     int n_items, n_objects, n_kd_nodes, n_inf, n_lights;
     int off_kd;        // 2 words per node: {int dim, int right} {double boundary | int first, int num}
-    int off_leaf;      // int32 pairs: object indices of all leaves
-    int off_inf;       // int32 pairs: infinite objects
+    int off_leaf;      // 1 word per reference {int object, int header flags}: items of all leaves
+    int off_inf;       // same, infinite objects
     int off_hdr;       // 2 words per object: {int flags, int param_off} {int aux0, int aux1}
     int off_bs;        // (N+2) words per object: center[N], radius, radius^2
     int off_bb;        // lower[N], upper[N]
-    int off_child;     // int32 pairs: nested primitives of composites
+    int off_child;     // same, nested primitives of composites
     int off_params;    // per-type parameter records
     int trace_words;   // everything above: what the trace kernel stages in LDS
     int off_mat;       // 8 words per object: rgb, reflect rgb, refract index, transparent
@@ -179,12 +179,21 @@ template <int N> NDT_DEV void v_refract(const double (&u)[N], double (&nrm)[N], 
     v_scale<N>(np, rp, ref_p);
     v_add<N>(ref_n, ref_p, res);
 }
-// a[i] for a runtime i without spilling the register array to scratch
+// a[i] for a runtime i, as a chain of v_cndmask on register values.  The empty asm makes each
+// element an opaque register value first: without it LLVM folds the select chain back into a
+// dynamically indexed load and the whole array (and everything else that was an alloca with
+// it) moves to scratch -- two L2 round trips per kd-tree step.
 template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
 {
-    double r = a[0];
+    double e0 = a[0];
+    asm volatile("" : "+v"(e0));
+    double r = e0;
 #pragma unroll
-    for (int k = 1; k < N; ++k) r = (i == k) ? a[k] : r;
+    for (int k = 1; k < N; ++k) {
+        double e = a[k];
+        asm volatile("" : "+v"(e));
+        r = (i == k) ? e : r;
+    }
     return r;
 }
 
@@ -196,10 +205,16 @@ NDT_DEV int blob_int(const double *blob, int word, int half)
 {
     return reinterpret_cast<const int *>(blob)[2 * word + half];
 }
-NDT_DEV int blob_int_at(const double *blob, int word_off, int idx)   // idx-th int32 of a packed section
+// one object reference {int object, int header flags} in a single 8-byte read
+NDT_DEV void blob_ref(const double *blob, int word, int &id, int &flags)
 {
-    return reinterpret_cast<const int *>(blob)[2 * word_off + idx];
+    const long long bits = __double_as_longlong(blob[word]);
+    id = (int)(bits & 0xffffffffll);
+    flags = (int)(bits >> 32);
 }
+// a kd node's two words in one 16-byte read (off_kd is 16-byte aligned)
+typedef double ndt_v2d __attribute__((ext_vector_type(2)));
+NDT_DEV ndt_v2d blob_pair(const double *blob, int word) { return *reinterpret_cast<const ndt_v2d *>(blob + word); }
 template <int N> NDT_DEV void blob_vec(const double *blob, int word, double (&r)[N])
 {
 #pragma unroll
@@ -671,30 +686,9 @@ template <int MW> struct VisitMask {
 #define NDT_KD_STACK 40
 #define NDT_STACK_FLAG 0x40000000   /* stack entry of the (unreachable) ray-parallel branch */
 
-// Traversal stack: one entry per pending far child, in a per-lane scratch array.  (A variant
-// that kept the top four entries in shifted registers measured 8 % slower on MI355X: the
-// kernel is instruction-issue bound, not scratch-latency bound; see DESIGN.md.)
-struct KdStack {
-    int s_node[NDT_KD_STACK];
-    double s_a[NDT_KD_STACK], s_tu[NDT_KD_STACK];
-    int n;
-    NDT_DEV void init() { n = 0; }
-    NDT_DEV bool empty() const { return n == 0; }
-    NDT_DEV void push(int node, double a, double tu)
-    {
-        s_node[n] = node;
-        s_a[n] = a;
-        s_tu[n] = tu;
-        ++n;
-    }
-    NDT_DEV void pop(int &node, double &a, double &tu)
-    {
-        --n;
-        node = s_node[n];
-        a = s_a[n];
-        tu = s_tu[n];
-    }
-};
+// Traversal stack: one entry per pending far child, in per-lane scratch arrays; the stack
+// pointer is a plain local so that it stays in a register (as a member of a struct holding the
+// arrays it lived in scratch too, and every push / pop paid two extra dependent round trips).
 
 #ifdef NDT_PHASE_TIMING
 // diagnostic build only: wave-level cycle stamps per phase (never enabled in the shipped library)
@@ -741,8 +735,9 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int l_obj = -1, l_prim = -1;
 
     // traversal state
-    KdStack stack;
-    stack.init();
+    int st_node[NDT_KD_STACK];
+    double st_a[NDT_KD_STACK], st_tu[NDT_KD_STACK];
+    int sp = 0;
     int node = 0;
     double ntl = 0, ntu = 0;
     bool have_node = false, started = false, done = false;
@@ -808,13 +803,14 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 have_node = true;
             }
             if (!have_node) {
-                if (stack.empty()) {
+                if (sp == 0) {
                     done = true;
                     break;
                 }
-                int nf;
-                double a;
-                stack.pop(nf, a, ntu);
+                --sp;
+                const int nf = st_node[sp];
+                const double a = st_a[sp];
+                ntu = st_tu[sp];
                 node = nf & ~NDT_STACK_FLAG;
                 // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
                 if (!(lt > a)) continue;
@@ -822,22 +818,24 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             }
             have_node = false;
             if (ntu < 0.0) continue;                    // kd-tree.c:490
-            const int k = sd.off_kd + 2 * node;
-            const int dim = blob_int(blob, k, 0);
+            const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
+            const long long w0 = __double_as_longlong(rec.x);
+            const int dim = (int)(w0 & 0xffffffffll);
             if (dim < 0) {
                 // leaf: trace() over its items (kd-tree.c:497-519)
-                const int num = blob_int(blob, k + 1, 1);
+                const long long w1 = __double_as_longlong(rec.y);
+                const int num = (int)(w1 >> 32);
                 if (num > 0) {
                     have_list = true;
                     list_is_inf = false;
                     sec = sd.off_leaf;
-                    pos = blob_int(blob, k + 1, 0);
+                    pos = (int)(w1 & 0xffffffffll);
                     end = pos + num;
                 }
                 continue;
             }
-            const double boundary = blob[k + 1];
-            int near = node + 1, far = blob_int(blob, k, 1);    // preorder: left child follows its parent
+            const double boundary = rec.y;
+            int near = node + 1, far = (int)(w0 >> 32);         // preorder: left child follows its parent
             const double v_inv_i = v_pick<N>(v_inv, dim);
             const double o_i = v_pick<N>(o, dim);
             if (v_inv_i < NDT_EPS2) {
@@ -855,7 +853,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     node = far; have_node = true;               // far only, same interval
                 } else {
                     if (lt > tp) {
-                        stack.push(far, tp, ntu);       // far: (tp-EPS, tu), gate tp
+                        st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
                     }
                     if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have_node = true; }
                 }
@@ -863,7 +861,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
                 // by construction), kept for fidelity with kd-tree.c:555-565
                 if (o_i > boundary - NDT_EPS) {
-                    stack.push(far | NDT_STACK_FLAG, ntl, ntu);
+                    st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
                 }
                 if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
             }
@@ -895,9 +893,9 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                         continue;
                     }
-                    const int p = blob_int_at(blob, sd.off_child, sub_i);
+                    int p, flags;
+                    blob_ref(blob, sd.off_child + sub_i, p, flags);
                     ++sub_i;
-                    const int flags = blob_int(blob, sd.off_hdr + 2 * p, 0);
                     if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, p, o, v, sub_min)) {
                         prim = p;
                         break;
@@ -905,12 +903,12 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     continue;
                 }
                 if (pos == end) break;
-                const int id = blob_int_at(blob, sec, pos);
+                int id, flags;
+                blob_ref(blob, sec + pos, id, flags);
                 ++pos;
                 if (!list_is_inf) {
                     if (mask.test_and_set(id)) continue;        // object.c:707-713
                 }
-                const int flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
                 // vect_object_intersect's gate (object.c:618-624), for composites too
                 if ((flags & NDT_F_GATE) && !bsphere_gate<N>(blob, sd, id, o, v, min_dist)) continue;
                 if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {

@@ -207,10 +207,15 @@ struct BlobBuilder {
         w.push_back(d);
         return words() - 1;
     }
-    int push_int_list(const std::vector<int> &v)
+    // object reference list: one word per entry {int object, int header flags}; the flags are
+    // patched in once the headers exist, so a list scan needs one LDS read per entry, not two
+    int push_ref_list(const std::vector<int> &v, std::vector<int> &patch)
     {
         int at = words();
-        for (size_t i = 0; i < v.size(); i += 2) push_ints(v[i], i + 1 < v.size() ? v[i + 1] : 0);
+        for (size_t i = 0; i < v.size(); ++i) {
+            patch.push_back(words());
+            push_ints(v[i], 0);
+        }
         if (v.empty()) push_ints(0, 0);
         return at;
     }
@@ -295,14 +300,15 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             for (int j = 0; j < k.num; ++j) leaf_list.push_back(fs->leaf_refs[k.first + j]);
         }
     }
-    sd.off_leaf = b.push_int_list(leaf_list);
+    std::vector<int> ref_patch;
+    sd.off_leaf = b.push_ref_list(leaf_list, ref_patch);
     std::vector<int> inf_list;
     for (int i = 0; i < fs->n_inf; ++i) {
         int id = fs->inf_refs[i];
         if (id < 0 || id >= fs->n_items) return fail(NDT_E_INVALID, "infinite list names object %d (n_items %d)", id, fs->n_items);
         inf_list.push_back(id);
     }
-    sd.off_inf = b.push_int_list(inf_list);
+    sd.off_inf = b.push_ref_list(inf_list, ref_patch);
 
     // ---- object headers (filled after params are placed), bounding spheres, root box
     sd.off_hdr = b.words();
@@ -339,7 +345,7 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             }
         }
     }
-    sd.off_child = b.push_int_list(child_list);
+    sd.off_child = b.push_ref_list(child_list, ref_patch);
 
     // ---- per-type parameters = the plugins' prepare() output
     sd.off_params = b.words();
@@ -489,6 +495,13 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         }
         b.set_ints(sd.off_hdr + 2 * i, flags, p);
         b.set_ints(sd.off_hdr + 2 * i + 1, aux0, aux1);
+    }
+    for (int w : ref_patch) {
+        int pair[2];
+        memcpy(pair, &b.w[w], sizeof(pair));
+        int hdr[2];
+        memcpy(hdr, &b.w[sd.off_hdr + 2 * pair[0]], sizeof(hdr));
+        b.set_ints(w, pair[0], hdr[0]);
     }
     sd.trace_words = b.words();
 

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 template <int MW, bool LDS>
 __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
-    extern __shared__ double lds_blob[];
+    extern __shared__ __attribute__((aligned(16))) double lds_blob[];
     const double *blob = gblob;
     if (LDS) {
         for (int i = threadIdx.x; i < sd.trace_words; i += blockDim.x) lds_blob[i] = gblob[i];

@@ -1,11 +1,38 @@
-import os, sys
-sys.path.insert(0, '/root/repo')
-import torch
-from ndt_amd import load_scene
+"""Per-launch timing probe for the trace kernel (development aid, not a test).
+usage: python profiles/levels_probe.py [--drop-type hcube] [--scene c3_random4d] [--res 1920x1080] [--depth 4]"""
+import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from ndt_amd import load_scene, OBJ_TYPES
 from ndt_amd.hip import NdtHip
-fs = load_scene('tests/golden/c3_random4d.ndtscene.gz')
-g = NdtHip(0); g.upload_scene(fs)
-for i in range(3): g.render(1920, 1080, 4)
-os.environ['NDT_HIP_DEBUG_LEVELS'] = '1'
-out, st = g.render(1920, 1080, 4, profile=1)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="c3_random4d")
+ap.add_argument("--res", default="1920x1080")
+ap.add_argument("--depth", type=int, default=4)
+ap.add_argument("--drop-type", default="")
+a = ap.parse_args()
+fs = load_scene("tests/golden/%s.ndtscene.gz" % a.scene)
+if a.drop_type:
+    t = OBJ_TYPES.index(a.drop_type)
+    drop = {i for i, o in enumerate(fs.objects) if o["type"] == t and o["parent"] < 0}
+    refs = []
+    for k in fs.kd_nodes:
+        if k["dim"] < 0:
+            ids = [i for i in fs.leaf_refs[k["first"]:k["first"] + k["num"]] if i not in drop]
+            k["first"], k["num"] = len(refs), len(ids)
+            refs.extend(ids)
+    fs.leaf_refs = refs
+    fs._struct = None
+    fs.finalize()
+    print("dropped %d objects of type %s from the leaves" % (len(drop), a.drop_type))
+w, h = (int(x) for x in a.res.split("x"))
+g = NdtHip(0)
+g.upload_scene(fs)
+for i in range(3):
+    g.render(w, h, a.depth)
+os.environ["NDT_HIP_DEBUG_LEVELS"] = "1"
+out, st = g.render(w, h, a.depth, profile=1)
 print(st.as_dict())
