@@ -67,6 +67,7 @@ struct ndt_hip_ctx {
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
     int *h_counters = nullptr;      // pinned
+    unsigned long long *h_ref = nullptr;   // pinned, 64 x 8
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -111,6 +112,13 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
         delete ctx;
         return fail(NDT_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
     }
+    e = hipHostMalloc((void **)&ctx->h_ref, 64 * 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipHostFree(ctx->h_counters);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(NDT_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
+    }
     *out = ctx;
     return NDT_OK;
 }
@@ -134,6 +142,7 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -636,7 +645,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.ref_rays, 2))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
     if ((rc = ws_alloc(ctx, &ws.dbg, 64))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -710,13 +719,31 @@ __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, Scene
         const double max_diff = 1.0 / 256.0;
         double clr_diff = 256;
         int samples = 0;
+        // Every sample is the same colour l, so the reference's
+        //     clr_diff = max_c |t_c/(i-1) - (t_c+l_c)/i|        (t = l+l+...+l, i terms)
+        // is max_c(l_c)/(i(i-1)) up to rounding (relative error < 4 i^2 ulp: a difference of two
+        // quotients of an i-term running sum).  The six divisions are only spent when that
+        // estimate lies inside the error band around 1/256; otherwise the loop-exit decision
+        // is already certain and identical to the exact one.
+        const double gb0 = (fabs(l[1]) > fabs(l[2])) ? fabs(l[1]) : fabs(l[2]);
+        const double lmax = (fabs(l[0]) > gb0) ? fabs(l[0]) : gb0;
+        const bool finite = lmax <= 1.0e300;          // false for inf / nan: always take the exact path
         for (int i = 0; i < 1 || (i < 10000 && clr_diff > max_diff); ++i) {
             if (i > 1) {
-                const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
-                const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
-                const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
-                const double gb = (dg > db) ? dg : db;      // MAX, image.h:31
-                clr_diff = (dr > gb) ? dr : gb;
+                const double ii = (double)i * (double)(i - 1);
+                const double est = lmax / ii;
+                const double band = 1.0e-15 * (8.0 * (double)i * (double)i) + 1.0e-12;
+                if (finite && est > max_diff * (1.0 + band)) {
+                    clr_diff = est;             // certainly still above the threshold: keep sampling
+                } else if (finite && est < max_diff * (1.0 - band)) {
+                    clr_diff = est;             // certainly converged: the loop ends here
+                } else {
+                    const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+                    const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+                    const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+                    const double gb = (dg > db) ? dg : db;      // MAX, image.h:31
+                    clr_diff = (dr > gb) ? dr : gb;
+                }
             }
             t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
             samples += 1;
@@ -728,9 +755,10 @@ __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, Scene
         out[3] = t[3] / samples;
         weighted = (unsigned long long)samples * (unsigned long long)ws.count[g];
     }
-    // one atomic per wavefront
+    // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
+    // saturates near 90 atomics/us, and there are 32k wavefronts at 1080p)
     for (int d = 32; d > 0; d >>= 1) weighted += __shfl_down(weighted, d, 64);
-    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays, weighted);
+    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), weighted);
 }
 
 // max_optic_depth <= 0: get_ray_color returns black without tracing (ndt.c:340)
@@ -823,9 +851,9 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         int *hc = ctx->h_counters;
         hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 2 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 64 * 8 * sizeof(unsigned long long), s));
         HIP_TRY(hipMemsetAsync(ws.dbg, 0, 64 * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_SLOTS * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)NDT_QUEUE_SLOTS * NDT_QUEUE_INTS * sizeof(int), s));
         int queue_slot = 0;
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
 
@@ -841,7 +869,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = nullptr; tj.valid = ws.depth_left; tj.n_seg = 0;
             tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = lr.begin; tj.count = lr.count;
             if (queue_slot + 2 > NDT_QUEUE_SLOTS) return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS / 2);
-            tj.queue = ws.counters + NDT_CNT_QUEUE + queue_slot++;
+            tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                 HIP_TRY(hipEventRecord(a, s));
@@ -869,7 +897,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 sj.o = ws.so; sj.v = ws.sv; sj.stride = ws.sh_cap; sj.lim = ws.slim; sj.valid = nullptr;
                 sj.seg_count = ws.counters + NDT_CNT_SEG; sj.seg_stride = lr.seg_stride; sj.n_seg = n_seg;
                 sj.out_obj = ws.sobj; sj.out_prim = ws.sprim; sj.begin = 0;
-                sj.queue = ws.counters + NDT_CNT_QUEUE + queue_slot++;
+                sj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
                 sj.count = lr.count * n_seg;        // upper bound, sizes the grid only
                 if (prof) {
                     hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
@@ -916,11 +944,11 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
                            rg, ctx->dims, (double *)d_rgba);
         unsigned long long ref_rays = 0;
-        HIP_TRY(hipMemcpyAsync(hc + 8, ws.ref_rays, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ctx->h_ref, ws.ref_rays, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if (prof) HIP_TRY(hipEventRecord(ev_end, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
-        memcpy(&ref_rays, hc + 8, sizeof(ref_rays));
+        for (int k = 0; k < 64; ++k) ref_rays += ctx->h_ref[8 * k];
         st.rays_primary = n_pixels;
         st.rays_secondary = (long long)hc[0] - rg.n_primary;
         st.rays_shadow = shadow_total;
@@ -1019,7 +1047,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = ws.frac; tj.valid = nullptr; tj.n_seg = 0;
     tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
-    HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());

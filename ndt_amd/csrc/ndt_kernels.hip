@@ -156,18 +156,40 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     } else {
         n_batches = (job.count + bs - 1) >> sh;
     }
+    // The batches are split into NDT_QUEUE_SHARDS contiguous shards, each with its own head on
+    // its own cache line: a single head word saturates near 90 pops/us on MI355X, which a
+    // 32k-batch launch would feel.  A wavefront drains its home shard (workgroup id mod shards,
+    // i.e. the workgroups that share an XCD) and then steals from the others; it exits when
+    // every shard is empty.
+    const long long per_shard = (n_batches + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+    int shard_try = 0;
+    const int home = blockIdx.x % NDT_QUEUE_SHARDS;
     while (true) {
-        int b = 0;
-        if (lane == 0) b = atomicAdd(job.queue, 1);
-        b = __shfl(b, 0, 64);
-        if (b >= n_batches) break;
+        long long b = -1;
+        while (shard_try < NDT_QUEUE_SHARDS) {
+            const int sh_i = (home + shard_try) % NDT_QUEUE_SHARDS;
+            const long long lo = sh_i * per_shard;
+            long long n_here = n_batches - lo;
+            if (n_here > per_shard) n_here = per_shard;
+            int k = 0;
+            if (n_here > 0) {
+                if (lane == 0) k = atomicAdd(job.queue + sh_i * NDT_QUEUE_STRIDE, 1);
+                k = __shfl(k, 0, 64);
+            }
+            if (n_here > 0 && k < n_here) {
+                b = lo + k;
+                break;
+            }
+            ++shard_try;       // this shard is drained for good
+        }
+        if (b < 0) break;
         long long g;
         if (job.n_seg > 0) {
             // segment of batch b = number of segments whose inclusive prefix is <= b
-            const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= b));
+            const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= (int)b));
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
             const int cnt = __shfl(seg_cnt, s, 64);
-            const int idx = (b - first) * bs + lane;
+            const int idx = ((int)b - first) * bs + lane;
             if (lane >= bs || idx >= cnt) continue;
             g = (long long)s * job.seg_stride + idx;
         } else {
@@ -342,44 +364,55 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
     // One shadow ray per light that passes the same-side / cone tests.  The queue is segmented
     // by light: the rays a wavefront later traces then share their origin (the light) and aim
     // at neighbouring hit points, instead of interleaving five unrelated origins.  Within a
-    // segment live rays are compacted with a wavefront ballot + one atomic per wavefront.
-    unsigned long long fire = 0ull;
+    // segment live rays are compacted with a wavefront ballot; the reservations of all
+    // segments go out as ONE atomic instruction (lane s reserves for segment s), so a wavefront
+    // waits for a single atomic round trip however many lights there are.
     const int lane = __lane_id();
-    int seg = 0;
+    unsigned long long fire = 0ull;
+    if (shaded) {
+        for (int li = 0; li < sd.n_lights; ++li) {
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+            ShadowSetup ss;
+            if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss)) fire |= 1ull << li;
+        }
+    }
+    // lane s learns how many lanes fire segment s's light, and which light that is
+    int my_total = 0, seg = 0;
     for (int li = 0; li < sd.n_lights; ++li) {
-        const int ltype = blob_int(blob, light_word(sd, li), 0);
-        if (ltype == NDT_LIGHT_AMBIENT_) continue;          // wave-uniform
-        int type = 0;
-        double lgt_pos[N], rev_light[N], light_vec[N], so[N];
-        ShadowSetup ss;
-        ss.dist_limit = 0;
-        ss.ldist2 = 1;
-        bool fires = false;
-        if (shaded) fires = light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;     // wave-uniform
+        const unsigned long long vote = __ballot((fire >> li) & 1ull);
+        if (lane == seg) my_total = __popcll(vote);
+        ++seg;
+    }
+    int my_base = 0;
+    if (my_total > 0) my_base = atomicAdd(&ws.counters[NDT_CNT_SEG + lane], my_total);
+    if (shaded) ws.sh_mask[g] = fire;
+    seg = 0;
+    for (int li = 0; li < sd.n_lights; ++li) {
+        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
+        const bool fires = (fire >> li) & 1ull;
         const unsigned long long vote = __ballot(fires);
-        const int total = __popcll(vote);
-        if (total > 0) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&ws.counters[NDT_CNT_SEG + seg], total);
-            base = __shfl(base, 0, 64);
-            if (fires) {
-                const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
-                const long long slot = (long long)seg * lr.seg_stride + idx;
-                ws.sh_idx[(long long)seg * ws.cap + g] = idx;
-                fire |= 1ull << li;
-                store_soa<N>(ws.so, ws.sh_cap, slot, so);
-                // point/spot: from the light along light_vec (ndt.c:211); directional: from the
-                // nudged hit point along rev_light (ndt.c:238)
-                if (type == NDT_LIGHT_DIRECTIONAL_)
-                    store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
-                else
-                    store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
-                ws.slim[slot] = ss.dist_limit;
-            }
+        const int base = __shfl(my_base, seg, 64);
+        if (fires) {
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+            ShadowSetup ss;
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
+            const long long slot = (long long)seg * lr.seg_stride + idx;
+            ws.sh_idx[(long long)seg * ws.cap + g] = idx;
+            store_soa<N>(ws.so, ws.sh_cap, slot, so);
+            // point/spot: from the light along light_vec (ndt.c:211); directional: from the
+            // nudged hit point along rev_light (ndt.c:238)
+            if (type == NDT_LIGHT_DIRECTIONAL_)
+                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
+            else
+                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
+            ws.slim[slot] = ss.dist_limit;
         }
         ++seg;
     }
-    if (shaded) ws.sh_mask[g] = fire;
 }
 
 // ------------------------------------------------------------------ shading, second half

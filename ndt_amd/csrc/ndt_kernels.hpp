@@ -29,7 +29,7 @@ struct Workspace {
     // counters: [0] node tail, [2] overflow flags (1 nodes, 2 shadows),
     // [NDT_CNT_QUEUE ..) work-queue heads, [NDT_CNT_SEG ..) shadow rays per light segment
     int *counters;
-    unsigned long long *ref_rays;   // [1] rays the reference would have traced (k-weighted)
+    unsigned long long *ref_rays;   // [64 x 8] partial sums (one 64-byte line each) of the rays the reference would have traced
     unsigned long long *mask_slab;  // visit masks for scenes too big for registers
     long long mask_slab_lanes;
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
@@ -88,9 +88,12 @@ extern "C" const NdtKernelTable *ndt_kernel_table_8();
 
 #define NDT_TRACE_BLOCK 256
 #define NDT_TRACE_MAX_BLOCK 768
-#define NDT_QUEUE_SLOTS 1024                /* work-queue heads per render call */
+#define NDT_QUEUE_SLOTS 512                 /* trace launches per render call that get a work queue */
+#define NDT_QUEUE_SHARDS 8                  /* queue heads per launch (one per XCD-sized group of workgroups) */
+#define NDT_QUEUE_STRIDE 16                 /* ints between heads: one 64-byte line each */
+#define NDT_QUEUE_INTS (NDT_QUEUE_SHARDS * NDT_QUEUE_STRIDE)
 #define NDT_CNT_QUEUE 16
-#define NDT_CNT_SEG (NDT_CNT_QUEUE + NDT_QUEUE_SLOTS)
+#define NDT_CNT_SEG (NDT_CNT_QUEUE + NDT_QUEUE_SLOTS * NDT_QUEUE_INTS)
 #define NDT_CNT_TOTAL (NDT_CNT_SEG + 64)
 #define NDT_TRACE_LDS_LIMIT (64 * 1024)     /* bytes of scene staged per workgroup: two workgroups per CU */
 #define NDT_MASK_REG_WORDS 4                /* 64-bit words of visit mask kept in registers (256 items) */
