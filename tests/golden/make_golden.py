@@ -43,6 +43,11 @@ CASES = {
     # configs[4] family at reduced size; 5-D exercises the odd-N lane-pair dot order
     "c5_hypercube4d": dict(scene="hypercube", dims=4, res=(64, 36), depth=128, fb=True, kat=1024),
     "c5_hypercube5d": dict(scene="hypercube", dims=5, res=(48, 27), depth=128, fb=True, kat=1024),
+    # configs[4]: 6-D .. 8-D hypercubes (728 / 2186 / 6560 objects): scenes too big for LDS and for
+    # a register visit mask, so these pin the global-memory tier of the trace kernel
+    "c5_hypercube6d": dict(scene="hypercube", dims=6, res=(48, 27), depth=128, fb=True, kat=512),
+    "c5_hypercube7d": dict(scene="hypercube", dims=7, res=(32, 18), depth=128, fb=True, kat=256),
+    "c5_hypercube8d": dict(scene="hypercube", dims=8, res=(24, 14), depth=128, fb=True, kat=128),
     # an animated frame: rotated hypercube, different tree
     "c1_hypercube3d_f37": dict(scene="hypercube", dims=3, res=(64, 64), depth=128, fb=True, kat=0, frame=37),
     # full BASELINE resolution, 8-bit (what the reference writes to PNG)

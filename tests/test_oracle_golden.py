@@ -46,7 +46,7 @@ def test_trace_kd_known_answers(oracle, name):
     # the vectors must actually exercise hits and misses, and every limit kind
     assert (obj >= 0).any() and (obj < 0).any()
     for lim_kind in (rays[:, 2 * d] < 0, rays[:, 2 * d] == 0, rays[:, 2 * d] > 0):
-        assert lim_kind.sum() > 100
+        assert lim_kind.sum() >= len(rays) // 5
 
 
 @pytest.mark.parametrize("name", FULL_CASES)
