@@ -61,12 +61,15 @@ def algorithmic_bytes_per_ray(dims):
     return 64 * dims + 168
 
 
-def cpu_baseline(workload, width, height, depth):
+def cpu_baseline(workload, width, height, depth, threads=16):
     """Time the reference itself (oracle/_ref, built from /root/reference by oracle/Makefile) on
     the host cores of this box, for the same frame.  Falls back to the oracle port if the
     reference build did not travel."""
     fixture, _, scene_so, dims, _ = WORKLOADS[workload]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box owns a 16-core share of the host; the reference's pthread path also stops
+    # scaling there (per-ray calloc/free + row imbalance: 256 threads are 2x SLOWER than 16)
+    cores = min(avail, threads)
     shim = os.path.join(ROOT, "oracle", "_ref", "ndt_ref_shim")
     if os.path.exists(shim):
         cmd = [shim, "--objects", os.path.join(ROOT, "oracle", "_ref", "objects"),
@@ -111,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="random4d", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="pthreads for the reference CPU baseline")
     ap.add_argument("--gather", default="f64", choices=["f64", "rgba8"], help="what the image gather moves")
     args = ap.parse_args()
 
@@ -129,7 +133,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from ndt_amd import load_scene, shard_rows
+    from ndt_amd import load_scene
     from ndt_amd.hip import NdtHip
 
     fixture, depth, _, dims, cfg_idx = WORKLOADS[args.workload]
@@ -138,30 +142,20 @@ def main():
     gpu = NdtHip(local_rank)
     gpu.upload_scene(fs)
 
-    rows_local = shard_rows(height, rank, world)
-    rows_max = shard_rows(height, 0, world)
-    local = torch.zeros((rows_max, width, 4), dtype=torch.float64, device="cuda")
-    local8 = torch.zeros((rows_max, width, 4), dtype=torch.uint8, device="cuda") if args.gather == "rgba8" else None
-    gathered = None
-    image = None
-    if world > 1 and rank == 0:
-        src = local8 if local8 is not None else local
-        gathered = [torch.empty_like(src) for _ in range(world)]
-        image = torch.empty((height, width, 4), dtype=src.dtype, device="cuda")
+    from ndt_amd.multi import RowGather
+    rg64 = RowGather(height, width, 4, torch.float64, "cuda", rank, world, dist)
+    rg8 = RowGather(height, width, 4, torch.uint8, "cuda", rank, world, dist) if args.gather == "rgba8" else None
+    local = rg64.local
 
     def step(profile):
         st = gpu.render_device(local.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
         if world > 1:
-            src = local
-            if local8 is not None:
-                gpu.quantize_device(local.data_ptr(), local8.data_ptr(), rows_max * width)
+            if rg8 is not None:
+                gpu.quantize_device(local.data_ptr(), rg8.local.data_ptr(), rg64.rows_max * width)
                 gpu.synchronize()
-                src = local8
-            dist.gather(src, gathered, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    n = shard_rows(height, r, world)
-                    image[r::world] = gathered[r][:n]
+                rg8.assemble()
+            else:
+                rg64.assemble()
         return st
 
     def fence():
@@ -246,7 +240,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth)
+            line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

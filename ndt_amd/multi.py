@@ -1,0 +1,44 @@
+"""Row-sharded rendering across ranks: one process per GPU, one gather to assemble the frame.
+
+Rows are dealt cyclically exactly like the reference's MPI_ROW mode (ndt.c:812-820): rank r
+renders image rows r, r+world, ...  Each rank holds its rows compactly; a single
+`torch.distributed.gather` (RCCL over xGMI on GPUs, gloo in the CPU tests) brings the shards to
+one rank, which de-interleaves them.  The reference instead sum-reduces full-size, mostly-zero
+images up a binary tree (ndt.c:1277-1309); that is an MPI convenience, not reproduced here.
+"""
+import torch
+
+from .flat_scene import shard_rows
+
+
+def padded_rows(height, world):
+    """Rows of the largest shard (every rank's buffer is padded to this for the gather)."""
+    return shard_rows(height, 0, world)
+
+
+class RowGather:
+    """Pre-allocated buffers + the gather/de-interleave step for one frame geometry."""
+
+    def __init__(self, height, width, channels, dtype, device, rank, world, dist=None, dst=0):
+        self.height, self.width, self.rank, self.world, self.dist, self.dst = height, width, rank, world, dist, dst
+        self.rows_max = padded_rows(height, world)
+        self.local = torch.zeros((self.rows_max, width, channels), dtype=dtype, device=device)
+        self.parts = None
+        self.image = None
+        if world > 1 and rank == dst:
+            self.parts = [torch.empty_like(self.local) for _ in range(world)]
+        if rank == dst:
+            self.image = torch.empty((height, width, channels), dtype=dtype, device=device)
+
+    def assemble(self):
+        """Gather every rank's `local` rows to `dst` and de-interleave; returns the frame on dst."""
+        if self.world == 1:
+            self.image.copy_(self.local[:self.height])
+            return self.image
+        self.dist.gather(self.local, self.parts, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            n = shard_rows(self.height, r, self.world)
+            self.image[r::self.world] = self.parts[r][:n]
+        return self.image
