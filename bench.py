@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="pthreads for the reference CPU baseline")
     ap.add_argument("--gather", default="f64", choices=["f64", "rgba8"], help="what the image gather moves")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 code path on a "
+                         "one-GPU box (all ranks share device 0, shards staged through host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,11 +130,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libndt_hip has no CPU path")
+    rehearsal = world > 1 and args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ndt_amd import load_scene
     from ndt_amd.hip import NdtHip
@@ -143,18 +152,26 @@ def main():
     gpu.upload_scene(fs)
 
     from ndt_amd.multi import RowGather
-    rg64 = RowGather(height, width, 4, torch.float64, "cuda", rank, world, dist)
-    rg8 = RowGather(height, width, 4, torch.uint8, "cuda", rank, world, dist) if args.gather == "rgba8" else None
-    local = rg64.local
+    gdev = "cpu" if rehearsal else "cuda"
+    rg64 = RowGather(height, width, 4, torch.float64, gdev, rank, world, dist)
+    rg8 = RowGather(height, width, 4, torch.uint8, gdev, rank, world, dist) if args.gather == "rgba8" else None
+    local = rg64.local if not rehearsal else torch.zeros_like(rg64.local, device="cuda")
+    local8 = None
+    if rg8 is not None:
+        local8 = rg8.local if not rehearsal else torch.zeros_like(rg8.local, device="cuda")
 
     def step(profile):
         st = gpu.render_device(local.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
         if world > 1:
             if rg8 is not None:
-                gpu.quantize_device(local.data_ptr(), rg8.local.data_ptr(), rg64.rows_max * width)
+                gpu.quantize_device(local.data_ptr(), local8.data_ptr(), rg64.rows_max * width)
                 gpu.synchronize()
+                if rehearsal:
+                    rg8.local.copy_(local8)
                 rg8.assemble()
             else:
+                if rehearsal:
+                    rg64.local.copy_(local)
                 rg64.assemble()
         return st
 
@@ -183,8 +200,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    counts = torch.tensor([agg["traced"], agg["ref_equiv"]], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([agg["traced"], agg["ref_equiv"]], dtype=torch.float64, device=gdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,7 +232,8 @@ def main():
                 "workload": "BASELINE configs[%d]: %s scene (tests/golden/%s.ndtscene.gz), %d-D, %dx%d, -l %d, "
                             "samples=1, mono, kd-tree on, specular on; rows cyclic over %d GPU(s)%s" % (
                                 cfg_idx, args.workload, fixture, dims, width, height, depth, world,
-                                ", RCCL gather of the %s image to rank 0" % args.gather if world > 1 else ""),
+                                ", %s gather of the %s image to rank 0" % ("RCCL" if not rehearsal else "gloo (rehearsal)", args.gather)
+                                if world > 1 else ""),
                 "width": width, "height": height, "dims": dims, "max_optic_depth": depth,
                 "parallelism": "rows%d" % world,
             },
