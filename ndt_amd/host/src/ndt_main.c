@@ -1,0 +1,134 @@
+/* ndt_main.c -- minimal frame-loop driver around the GPU path, accepting the flags the
+ * BASELINE configs use (reference ndt.c:1450: -d -r -f -l -s -t -u -o).  It loads a scene
+ * program exactly like the reference does (dlopen + dlsym scene_setup / scene_frames /
+ * scene_cleanup, ndt.c:1654-1664), renders each frame with ndt_render_image and writes
+ * images/<scene>/<N>d/<WxH>/<scene>_<WxH>_<frame>.ppm (binary PPM of the pixel_d2c bytes; PNG
+ * / JPEG encoding is outside this repository's scope).  `--dump-scene F` writes the flattened
+ * scene of the last frame as an ndtscene file instead of rendering. */
+#include <dlfcn.h>
+#include <getopt.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include "ndt_host_internal.h"
+
+static double now_s(void)
+{
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+static int write_ppm(const char *path, const double *rgba, int w, int h)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    for (long i = 0; i < (long)w * h; ++i) {
+        unsigned char px[3];
+        for (int c = 0; c < 3; ++c) {
+            double d = rgba[4 * i + c];
+            double m = (1.0 < d) ? 1.0 : d;                 /* pixel_d2c, image.h:36-39 */
+            m = (0.0 > m) ? 0.0 : m;
+            px[c] = (unsigned char)(sqrt(m) * 255);
+        }
+        fwrite(px, 1, 3, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
+    int depth = 128, threads = 1;
+    char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
+    static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
+                                        { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
+    int ch;
+    while ((ch = getopt_long(argc, argv, "d:r:f:l:s:t:u:o:h", longopts, NULL)) != -1) {
+        int a1, a2, a3, n;
+        switch (ch) {
+        case 'd': dims = atoi(optarg); break;
+        case 'r':
+            if (!strcmp(optarg, "4k")) { width = 3840; height = 2160; }
+            else if (!strcmp(optarg, "1080p")) { width = 1920; height = 1080; }
+            else if (!strcmp(optarg, "720p")) { width = 1280; height = 720; }
+            else if (!strcmp(optarg, "480p")) { width = 720; height = 480; }
+            else sscanf(optarg, "%dx%d", &width, &height);
+            break;
+        case 'f':       /* first:last:total, first:last, or last (ndt.c:1510-1524) */
+            n = sscanf(optarg, "%d:%d:%d", &a1, &a2, &a3);
+            if (n >= 3) { first = a1; last = a2; frames = a3; frames_given = 1; }
+            else if (n >= 2) { first = a1; last = a2; }
+            else if (n >= 1) { last = a1; }
+            break;
+        case 'l': depth = atoi(optarg); break;
+        case 's': scene_path = optarg; break;
+        case 't': threads = atoi(optarg); break;
+        case 'u': config = optarg; break;
+        case 'o': break;    /* object plugins are built in */
+        case 1000: dump_path = optarg; break;
+        case 1001: raw_path = optarg; break;
+        default:
+            fprintf(stderr, "usage: %s -s scene.so [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
+                            "          [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+            return ch == 'h' ? 0 : 1;
+        }
+    }
+    if (!scene_path || dims < 3 || width < 1 || height < 1) {
+        fprintf(stderr, "%s: need -s scene.so, dims >= 3 and a resolution\n", argv[0]);
+        return 1;
+    }
+    void *dl = dlopen(scene_path, RTLD_NOW);
+    if (!dl) { fprintf(stderr, "%s\n", dlerror()); return 1; }
+    int (*setup)(scene *, int, int, int, char *) = NULL;
+    int (*frame_count)(int, char *) = NULL;
+    int (*cleanup)(void) = NULL;
+    *(void **)(&setup) = dlsym(dl, "scene_setup");
+    *(void **)(&frame_count) = dlsym(dl, "scene_frames");
+    *(void **)(&cleanup) = dlsym(dl, "scene_cleanup");
+    if (!setup) { fprintf(stderr, "%s has no scene_setup\n", scene_path); return 1; }
+    if (frame_count && !frames_given) frames = frame_count(dims, config);
+    if (last < 0) last = frames - 1;
+    register_objects("objects");
+
+    double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+    for (int i = 0; i < frames && i <= last; ++i) {
+        scene scn;
+        setup(&scn, dims, i, frames, config);
+        if (i < first) {            /* earlier frames still run scene_setup (ndt.c:1818-1825) */
+            scene_free(&scn);
+            continue;
+        }
+        printf("Scene has %i objects and %i lights\n", scn.num_objects, scn.num_lights);
+        if (dump_path) {
+            char err[256];
+            ndt_flat_builder fb;
+            if (ndt_flatten_scene(&scn, &fb, err, sizeof(err)) != 0) { fprintf(stderr, "%s\n", err); return 1; }
+            if (i == last || i == frames - 1) ndt_write_ndtscene(&fb.fs, scn.name, dump_path);
+            ndt_flat_builder_free(&fb);
+            scene_free(&scn);
+            continue;
+        }
+        double t0 = now_s();
+        if (!ndt_render_image(&scn, width, height, threads, depth, rgba)) return 1;
+        printf("rendering took %.3fs\n", now_s() - t0);
+        char dir[512], path[1024];
+        mkdir("images", 0700);
+        snprintf(dir, sizeof(dir), "images/%s", scn.name); mkdir(dir, 0700);
+        snprintf(dir, sizeof(dir), "images/%s/%id", scn.name, dims); mkdir(dir, 0700);
+        snprintf(dir, sizeof(dir), "images/%s/%id/%ix%i", scn.name, dims, width, height); mkdir(dir, 0700);
+        snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn.name, width, height, i);
+        write_ppm(path, rgba, width, height);
+        printf("\tsaved %s\n", path);
+        if (raw_path) {
+            FILE *f = fopen(raw_path, "wb");
+            if (f) { fwrite(rgba, sizeof(double), (size_t)width * height * 4, f); fclose(f); }
+        }
+        scene_free(&scn);
+    }
+    free(rgba);
+    if (cleanup) cleanup();
+    return 0;
+}

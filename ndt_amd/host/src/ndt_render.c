@@ -1,0 +1,32 @@
+/* ndt_render.c -- render_image (reference ndt.c:900) for this host model: flatten, upload,
+ * render on the GPU through the C ABI of include/ndt_hip.h.  No CPU rendering exists here. */
+#include "ndt_host_internal.h"
+
+static ndt_hip_ctx *g_ctx = NULL;
+
+int ndt_render_image(scene *scn, int width, int height, int threads, int max_optic_depth, double *rgba)
+{
+    (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
+    char err[256];
+    ndt_flat_builder fb;
+    if (ndt_flatten_scene(scn, &fb, err, sizeof(err)) != 0) {
+        fprintf(stderr, "ndt_render_image: %s\n", err);
+        ndt_flat_builder_free(&fb);
+        return 0;
+    }
+    int ok = 0;
+    if (!g_ctx && ndt_hip_create(0, &g_ctx) != NDT_OK) {
+        fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
+    } else if (ndt_hip_upload_scene(g_ctx, &fb.fs) != NDT_OK) {
+        fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
+    } else {
+        ndt_render_params p;
+        memset(&p, 0, sizeof(p));
+        p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = 1;
+        p.row_begin = 0; p.row_step = 1; p.specular = 1;
+        if (ndt_hip_render(g_ctx, &p, rgba, NULL) == NDT_OK) ok = 1;
+        else fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
+    }
+    ndt_flat_builder_free(&fb);
+    return ok;
+}

@@ -1,0 +1,100 @@
+"""The host half of the drop-in: ndt's scene / object / camera C API re-implemented in
+ndt_amd/host (libndt_host.so + the ndt_hip driver).
+
+Scene programs are the reference's own, unmodified:
+  * built from source against THIS repo's headers (needs /root/reference: build container), and
+  * the binaries oracle/_ref/scenes/*.so that were compiled against the REFERENCE's headers
+    (struct layouts are ABI; these travel to the GPU box).
+Either way the flattened scene our host produces -- bounding spheres from our Nelder-Mead,
+our kd-tree build, our camera_aim, our hcube faces -- must equal, byte for byte, the scene the
+compiled reference produced (tests/golden/*.ndtscene.gz).
+"""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN, golden
+
+HOST = os.path.join(ROOT, "ndt_amd", "host")
+DRIVER = os.path.join(HOST, "ndt_hip")
+REF_SRC = "/root/reference/scenes"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "scenes")
+
+# fixture -> (scene program, dims, frame)
+CASES = {
+    "c1_hypercube3d": ("hypercube", 3, 0),
+    "c1_hypercube3d_f37": ("hypercube", 3, 37),
+    "c2_balls4d": ("balls", 4, 0),
+    "c3_random4d": ("random", 4, 0),
+    "c5_hypercube4d": ("hypercube", 4, 0),
+    "c5_hypercube5d": ("hypercube", 5, 0),
+    "c5_hypercube6d": ("hypercube", 6, 0),
+    "c5_hypercube7d": ("hypercube", 7, 0),
+}
+
+
+@pytest.fixture(scope="module")
+def driver():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "ndt_amd", "csrc"), "-j", "8"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", HOST], check=True, capture_output=True)
+    assert os.path.exists(DRIVER)
+    return DRIVER
+
+
+def _fixture_text(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".ndtscene.gz"), "rt") as f:
+        return f.read()
+
+
+def _dump(driver, scene_so, dims, frame, out):
+    r = subprocess.run([driver, "-s", scene_so, "-d", str(dims), "-f", "%d:%d" % (frame, frame), "--dump-scene", out],
+                       capture_output=True, text=True, cwd=os.path.dirname(out))
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(out) as f:
+        return f.read()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference sources only exist in the build container")
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_scene_sources_compile_unchanged_and_flatten_identically(driver, tmp_path, name):
+    prog, dims, frame = CASES[name]
+    # scenes say #include "../scene.h": lay the tree out so that resolves to our headers
+    (tmp_path / "scenes").mkdir()
+    for h in os.listdir(os.path.join(HOST, "include")):
+        os.symlink(os.path.join(HOST, "include", h), tmp_path / h)
+    os.symlink(os.path.join(REF_SRC, prog + ".c"), tmp_path / "scenes" / (prog + ".c"))
+    so = str(tmp_path / "scenes" / (prog + ".so"))
+    r = subprocess.run(["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-fPIC", "-shared", "-Wall", "-o", so,
+                        str(tmp_path / "scenes" / (prog + ".c"))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene")) == _fixture_text(name)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built (make -C oracle ref)")
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_built_scene_binaries_load_unchanged(driver, tmp_path, name):
+    prog, dims, frame = CASES[name]
+    so = os.path.join(REF_BIN, prog + ".so")
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene")) == _fixture_text(name)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube6d"])
+def test_end_to_end_reference_scene_to_pixels(driver, tmp_path, name):
+    """The whole drop-in: the reference's scene binary -> our host API -> flatten -> GPU ->
+    the framebuffer the compiled reference rendered."""
+    prog, dims, frame = CASES[name]
+    g = golden(name)
+    raw = str(tmp_path / "fb.f64")
+    r = subprocess.run([driver, "-s", os.path.join(REF_BIN, prog + ".so"), "-d", str(dims), "-f", "0",
+                        "-r", "%dx%d" % (g.width, g.height), "-l", str(g.depth), "--raw", raw],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    fb = np.fromfile(raw).reshape(g.height, g.width, 4)
+    assert np.abs(fb - g.data["fb"]).max() < 1e-9
+    ppm = [p for p in (tmp_path / "images").rglob("*.ppm")]
+    assert len(ppm) == 1
