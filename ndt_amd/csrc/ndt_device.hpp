@@ -740,7 +740,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int sp = 0;
     int node = 0;
     double ntl = 0, ntu = 0;
-    bool have_node = false, started = false, done = false;
+    bool have_node = false, done = false;
 
     // current list
     bool have_list = false, list_is_inf = false;
@@ -761,109 +761,115 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
         end = sd.n_inf;
     }
 
+    // The inner loops below are written with ONE back edge each and if/else bodies (no
+    // `continue` / `break`): hipcc then emits one structured loop per phase instead of the nest
+    // of exec-mask bookkeeping loops it builds for early-continue code, which cost about as many
+    // scalar instructions as the arithmetic itself.
+    bool root_pending = true;       // the root box has not been tested yet
     while (true) {
         // ------------------------------------------------------------ phase T
-        while (!have_list && !done) {
-            if (!started) {
-                started = true;
-                // aabb_intersect on the root box, kd-tree.c:84-127
-                double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
-                bool box = true;
+        if (!have_list && !done && root_pending) {
+            root_pending = false;
+            // aabb_intersect on the root box, kd-tree.c:84-127
+            double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
+            bool box = true;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    if (box) {
-                        double v_i = v[i], o_i = o[i];
-                        if (!(fabs(v_i) < NDT_EPS2)) {
-                            double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
-                            double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
-                            if (tl_i > tu_i) {
-                                double tmp = tl_i;
-                                tl_i = tu_i;
-                                tu_i = tmp;
-                            }
-                            if (tl_i > tl) tl = tl_i;
-                            if (tu_i < tu) tu = tu_i;
-                            if (tu < -NDT_EPS) box = false;
+            for (int i = 0; i < N; ++i) {
+                if (box) {
+                    double v_i = v[i], o_i = o[i];
+                    if (!(fabs(v_i) < NDT_EPS2)) {
+                        double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
+                        double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
+                        if (tl_i > tu_i) {
+                            double tmp = tl_i;
+                            tl_i = tu_i;
+                            tu_i = tmp;
                         }
+                        if (tl_i > tl) tl = tl_i;
+                        if (tu_i < tu) tu = tu_i;
+                        if (tu < -NDT_EPS) box = false;
                     }
                 }
-                if (box) {
-                    tl -= NDT_EPS;
-                    tu += NDT_EPS;
-                    box = (tu >= -NDT_EPS) && (tl <= tu);
-                }
-                if (!box || sd.n_kd_nodes <= 0) {
-                    done = true;
-                    break;
-                }
+            }
+            if (box) {
+                tl -= NDT_EPS;
+                tu += NDT_EPS;
+                box = (tu >= -NDT_EPS) && (tl <= tu);
+            }
+            if (!box || sd.n_kd_nodes <= 0) {
+                done = true;
+            } else {
                 mask.clear(sd.mask_words);
                 node = 0;
                 ntl = tl;
                 ntu = tu;
                 have_node = true;
             }
+        }
+        while (!have_list && !done) {
+            bool visit = have_node;
             if (!have_node) {
                 if (sp == 0) {
                     done = true;
-                    break;
+                } else {
+                    --sp;
+                    const int nf = st_node[sp];
+                    const double a = st_a[sp];
+                    ntu = st_tu[sp];
+                    node = nf & ~NDT_STACK_FLAG;
+                    ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
+                    // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
+                    visit = lt > a;
                 }
-                --sp;
-                const int nf = st_node[sp];
-                const double a = st_a[sp];
-                ntu = st_tu[sp];
-                node = nf & ~NDT_STACK_FLAG;
-                // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
-                if (!(lt > a)) continue;
-                ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
             }
             have_node = false;
-            if (ntu < 0.0) continue;                    // kd-tree.c:490
-            const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
-            const long long w0 = __double_as_longlong(rec.x);
-            const int dim = (int)(w0 & 0xffffffffll);
-            if (dim < 0) {
-                // leaf: trace() over its items (kd-tree.c:497-519)
-                const long long w1 = __double_as_longlong(rec.y);
-                const int num = (int)(w1 >> 32);
-                if (num > 0) {
-                    have_list = true;
-                    list_is_inf = false;
-                    sec = sd.off_leaf;
-                    pos = (int)(w1 & 0xffffffffll);
-                    end = pos + num;
-                }
-                continue;
-            }
-            const double boundary = rec.y;
-            int near = node + 1, far = (int)(w0 >> 32);         // preorder: left child follows its parent
-            const double v_inv_i = v_pick<N>(v_inv, dim);
-            const double o_i = v_pick<N>(o, dim);
-            if (v_inv_i < NDT_EPS2) {
-                int tmp = near;
-                near = far;
-                far = tmp;
-            }
-            if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
-                const double tp = (boundary - o_i) * v_inv_i;
-                // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before
-                // pushing the far child is safe; the test that counts is repeated at pop time.
-                if (ntu < tp - NDT_EPS && lt > ntl) {
-                    node = near; have_node = true;              // near only, same interval
-                } else if (ntl > tp + NDT_EPS && lt > ntl) {
-                    node = far; have_node = true;               // far only, same interval
-                } else {
-                    if (lt > tp) {
-                        st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
+            if (visit && !(ntu < 0.0)) {                 // kd-tree.c:490
+                const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
+                const long long w0 = __double_as_longlong(rec.x);
+                const int dim = (int)(w0 & 0xffffffffll);
+                if (dim < 0) {
+                    // leaf: trace() over its items (kd-tree.c:497-519)
+                    const long long w1 = __double_as_longlong(rec.y);
+                    const int num = (int)(w1 >> 32);
+                    if (num > 0) {
+                        have_list = true;
+                        list_is_inf = false;
+                        sec = sd.off_leaf;
+                        pos = (int)(w1 & 0xffffffffll);
+                        end = pos + num;
                     }
-                    if (lt > ntl) { node = near; ntu = tp + NDT_EPS; have_node = true; }
+                } else {
+                    const double boundary = rec.y;
+                    const double v_inv_i = v_pick<N>(v_inv, dim);
+                    const double o_i = v_pick<N>(o, dim);
+                    // preorder: the left child follows its parent; swap for negative directions
+                    const bool swap = v_inv_i < NDT_EPS2;
+                    const int left = node + 1, right = (int)(w0 >> 32);
+                    const int near = swap ? right : left, far = swap ? left : right;
+                    if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
+                        const double tp = (boundary - o_i) * v_inv_i;
+                        const bool alive = lt > ntl;
+                        // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before
+                        // pushing the far child is safe; the test that counts is repeated at pop time.
+                        if (ntu < tp - NDT_EPS && alive) {
+                            node = near; have_node = true;              // near only, same interval
+                        } else if (ntl > tp + NDT_EPS && alive) {
+                            node = far; have_node = true;               // far only, same interval
+                        } else {
+                            if (lt > tp) {
+                                st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
+                            }
+                            if (alive) { node = near; ntu = tp + NDT_EPS; have_node = true; }
+                        }
+                    } else {
+                        // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
+                        // by construction), kept for fidelity with kd-tree.c:555-565
+                        if (o_i > boundary - NDT_EPS) {
+                            st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
+                        }
+                        if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
+                    }
                 }
-            } else {
-                // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
-                // by construction), kept for fidelity with kd-tree.c:555-565
-                if (o_i > boundary - NDT_EPS) {
-                    st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
-                }
-                if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
             }
         }
         NDT_STAMP(0);
@@ -873,80 +879,80 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
         min_dist = -1;
         best_obj = -1;
         best_prim = -1;
-        while (true) {
+        bool list_open = true;
+        while (list_open) {
             // ---- phase G: advance to the next primitive that passes its gate
             int prim = -1;
-            while (true) {
-                if (in_sub) {
-                    if (sub_i == sub_end) {
-                        // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
-                        // then the outer trace() applies its accept / break rules
-                        in_sub = false;
-                        if (sub_min >= 0) {
-                            const double dist = sub_min;    // == |o - res| of the accepted face
-                            if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {
-                                min_dist = dist;
-                                best_obj = sub_owner;
-                                best_prim = sub_prim;
-                            }
-                            if (dist_limit == 0.0 || dist < dist_limit) pos = end;      // break
+            bool scanning = true;
+            while (scanning) {
+                if (in_sub && sub_i == sub_end) {
+                    // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
+                    // then the outer trace() applies its accept / break rules
+                    in_sub = false;
+                    if (sub_min >= 0) {
+                        const double dist = sub_min;    // == |o - res| of the accepted face
+                        if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {
+                            min_dist = dist;
+                            best_obj = sub_owner;
+                            best_prim = sub_prim;
                         }
-                        continue;
+                        if (dist_limit == 0.0 || dist < dist_limit) pos = end;      // break
                     }
-                    int p, flags;
-                    blob_ref(blob, sd.off_child + sub_i, p, flags);
-                    ++sub_i;
-                    if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, p, o, v, sub_min)) {
-                        prim = p;
-                        break;
+                } else if (!in_sub && pos == end) {
+                    scanning = false;       // list exhausted
+                } else {
+                    int id, flags;
+                    blob_ref(blob, in_sub ? sd.off_child + sub_i : sec + pos, id, flags);
+                    sub_i += in_sub ? 1 : 0;
+                    pos += in_sub ? 0 : 1;
+                    bool fresh = true;
+                    if (!in_sub && !list_is_inf) fresh = !mask.test_and_set(id);    // object.c:707-713
+                    if (fresh) {
+                        // vect_object_intersect's gate (object.c:618-624), for composites too
+                        const double gate_min = in_sub ? sub_min : min_dist;
+                        if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, id, o, v, gate_min)) {
+                            if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
+                                // composites only occur in outer lists (validated at upload)
+                                in_sub = true;
+                                sub_owner = id;
+                                sub_i = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
+                                sub_end = sub_i + blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+                                sub_min = -1;
+                                sub_prim = -1;
+                            } else {
+                                prim = id;
+                                scanning = false;
+                            }
+                        }
                     }
-                    continue;
                 }
-                if (pos == end) break;
-                int id, flags;
-                blob_ref(blob, sec + pos, id, flags);
-                ++pos;
-                if (!list_is_inf) {
-                    if (mask.test_and_set(id)) continue;        // object.c:707-713
-                }
-                // vect_object_intersect's gate (object.c:618-624), for composites too
-                if ((flags & NDT_F_GATE) && !bsphere_gate<N>(blob, sd, id, o, v, min_dist)) continue;
-                if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
-                    in_sub = true;
-                    sub_owner = id;
-                    sub_i = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
-                    sub_end = sub_i + blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
-                    sub_min = -1;
-                    sub_prim = -1;
-                    continue;
-                }
-                prim = id;
-                break;
             }
             NDT_STAMP(1);
-            if (prim < 0) break;        // list exhausted
-
-            // ---- phase I: intersect
-            double res[N], nrm[N];
-            const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
-            if (ok) {
-                const double dist = v_dist<N>(o, res);          // object.c:721
-                if (in_sub) {
-                    // inner trace(): dist_limit = -1, no mask (hcube.c:241)
-                    if (dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
-                        sub_min = dist;
-                        sub_prim = prim;
+            if (prim < 0) {
+                list_open = false;
+            } else {
+                // ---- phase I: intersect
+                double res[N], nrm[N];
+                const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
+                if (ok) {
+                    const double dist = v_dist<N>(o, res);          // object.c:721
+                    if (in_sub) {
+                        // inner trace(): dist_limit = -1, no mask (hcube.c:241)
+                        if (dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
+                            sub_min = dist;
+                            sub_prim = prim;
+                        }
+                    } else {
+                        if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {       // object.c:722
+                            min_dist = dist;
+                            best_obj = prim;
+                            best_prim = prim;
+                        }
+                        if (dist_limit == 0.0 || dist < dist_limit) pos = end;                      // object.c:730
                     }
-                } else {
-                    if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {       // object.c:722
-                        min_dist = dist;
-                        best_obj = prim;
-                        best_prim = prim;
-                    }
-                    if (dist_limit == 0.0 || dist < dist_limit) pos = end;                      // object.c:730
                 }
+                NDT_STAMP(2);
             }
-            NDT_STAMP(2);
         }
 
         // ---- list finished: what trace() returns to its caller
