@@ -698,15 +698,17 @@ template <int MW> struct VisitMask {
         ph[slot] += now_ - ph_last;                                       \
         ph_last = now_;                                                   \
     } while (0)
+#define NDT_COUNT(slot) (cnt[slot] += 1)
 #else
 #define NDT_STAMP(slot) do { } while (0)
+#define NDT_COUNT(slot) do { } while (0)
 #endif
 
 template <int N, int MW>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
-                      , unsigned long long (&ph)[4]
+                      , unsigned long long (&ph)[4], unsigned int (&cnt)[8]
 #endif
                       )
 {
@@ -824,6 +826,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             }
             have_node = false;
             if (visit && !(ntu < 0.0)) {                 // kd-tree.c:490
+                NDT_COUNT(0);
                 const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
                 const long long w0 = __double_as_longlong(rec.x);
                 const int dim = (int)(w0 & 0xffffffffll);
@@ -910,6 +913,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     if (fresh) {
                         // vect_object_intersect's gate (object.c:618-624), for composites too
                         const double gate_min = in_sub ? sub_min : min_dist;
+                        if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
                         if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, id, o, v, gate_min)) {
                             if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
                                 // composites only occur in outer lists (validated at upload)
@@ -922,6 +926,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             } else {
                                 prim = id;
                                 scanning = false;
+                                if (in_sub) NDT_COUNT(2); else NDT_COUNT(4);
                             }
                         }
                     }
@@ -935,6 +940,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 double res[N], nrm[N];
                 const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
                 if (ok) {
+                    NDT_COUNT(5);
                     const double dist = v_dist<N>(o, res);          // object.c:721
                     if (in_sub) {
                         // inner trace(): dist_limit = -1, no mask (hcube.c:241)

@@ -204,7 +204,12 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         const double lim = job.lim ? job.lim[g] : -1.0;
         int obj, prim;
 #ifdef NDT_PHASE_TIMING
-        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph);
+        unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt);
+        if (ws.dbg) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[8 + i], (unsigned long long)cnt[i]);
+            atomicAdd(&ws.dbg[14], 1ull);
+        }
 #else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
 #endif
@@ -427,7 +432,6 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
     if (in_range && ws.depth_left[g] > 0) obj = ws.hit_obj[g];
     const bool shaded = obj >= 0;
 
-    int n_child = 0;
     bool want_refl = false, want_refr = false;
     double refl_ray[N], refr_ray[N], hit[N];
     double refl_frac = 0, refr_frac = 0;
@@ -541,40 +545,43 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
         }
         ws.child_refl[g] = c_refl;
         ws.child_refr[g] = c_refr;
-        n_child = (want_refl ? 1 : 0) + (want_refr ? 1 : 0);
     }
-    int total;
-    const int rank = wave_excl_scan(n_child, total);
+    // Compact the children of this wavefront into the next bounce: one reservation per
+    // wavefront, reflection rays first and refraction rays after them, so that the wavefronts
+    // of the next bounce hold one kind of ray (the two kinds leave a surface in unrelated
+    // directions and would diverge from the first tree node on).
+    const int lane = __lane_id();
+    const unsigned long long v_refl = __ballot(want_refl), v_refr = __ballot(want_refr);
+    const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
     const int base = wave_reserve(&ws.counters[0], total);
     if (total > 0 && (long long)base + total > ws.cap) {
-        if (__lane_id() == 0) atomicOr(&ws.counters[2], 1);
+        if (lane == 0) atomicOr(&ws.counters[2], 1);
         return;
     }
-    if (n_child > 0) {
-        long long c = (long long)base + rank;
-        if (want_refl) {
-            store_soa<N>(ws.ray_o, ws.cap, c, hit);
-            store_soa<N>(ws.ray_v, ws.cap, c, refl_ray);
-            ws.frac[c] = refl_frac;
-            ws.depth_left[c] = depth_next;
-            ws.child_refl[c] = -1;
-            ws.child_refr[c] = -1;
-            ws.count[c] = 0;
-            ws.sh_mask[c] = 0ull;
-            ws.child_refl[g] = (int)c;
-            ++c;
-        }
-        if (want_refr) {
-            store_soa<N>(ws.ray_o, ws.cap, c, hit);
-            store_soa<N>(ws.ray_v, ws.cap, c, refr_ray);
-            ws.frac[c] = refr_frac;
-            ws.depth_left[c] = depth_next;
-            ws.child_refl[c] = -1;
-            ws.child_refr[c] = -1;
-            ws.count[c] = 0;
-            ws.sh_mask[c] = 0ull;
-            ws.child_refr[g] = (int)c;
-        }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (want_refl) {
+        const long long c = (long long)base + __popcll(v_refl & below);
+        store_soa<N>(ws.ray_o, ws.cap, c, hit);
+        store_soa<N>(ws.ray_v, ws.cap, c, refl_ray);
+        ws.frac[c] = refl_frac;
+        ws.depth_left[c] = depth_next;
+        ws.child_refl[c] = -1;
+        ws.child_refr[c] = -1;
+        ws.count[c] = 0;
+        ws.sh_mask[c] = 0ull;
+        ws.child_refl[g] = (int)c;
+    }
+    if (want_refr) {
+        const long long c = (long long)base + n_refl + __popcll(v_refr & below);
+        store_soa<N>(ws.ray_o, ws.cap, c, hit);
+        store_soa<N>(ws.ray_v, ws.cap, c, refr_ray);
+        ws.frac[c] = refr_frac;
+        ws.depth_left[c] = depth_next;
+        ws.child_refl[c] = -1;
+        ws.child_refr[c] = -1;
+        ws.count[c] = 0;
+        ws.sh_mask[c] = 0ull;
+        ws.child_refr[g] = (int)c;
     }
 }
 
