@@ -61,6 +61,17 @@ def algorithmic_bytes_per_ray(dims):
     return 64 * dims + 168
 
 
+def pmc_traffic(workload, width, height):
+    """HBM bytes per k_trace launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+    gfx950 correction, calibrated on k_finish_pixels; + WRITE_SIZE) -- profiles/make_traffic_json.py.
+    Counters cannot be read from inside a run, so this is the profile of the same command."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_%s_%dp.json" % (workload, height))
+    if width != 1920 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["trace"]["hbm_bytes_per_launch"])
+
+
 def cpu_baseline(workload, width, height, depth, threads=16):
     """Time the reference itself (oracle/_ref, built from /root/reference by oracle/Makefile) on
     the host cores of this box, for the same frame.  Falls back to the oracle port if the
@@ -250,7 +261,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload, width, height) if world == 1 else None,
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_traffic_*.json)",
+                "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
                 "bytes_per_ray": bytes_per_ray,
                 "rays_per_launch": rays_per_launch,
                 "avg_launch_ms": avg_launch_ms,
