@@ -91,7 +91,8 @@ def golden(name):
 
 
 SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4d", "c5_hypercube4d",
-               "c5_hypercube5d", "c5_hypercube6d", "c5_hypercube7d", "c5_hypercube8d"]
+               "c5_hypercube5d", "c5_hypercube6d", "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror",
+               "zoo5d_f2", "zoo6d"]
 KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d", "c5_hypercube6d",
-             "c5_hypercube7d", "c5_hypercube8d"]
+             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d"]
 FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]

@@ -48,6 +48,13 @@ CASES = {
     "c5_hypercube6d": dict(scene="hypercube", dims=6, res=(48, 27), depth=128, fb=True, kat=512),
     "c5_hypercube7d": dict(scene="hypercube", dims=7, res=(32, 18), depth=128, fb=True, kat=256),
     "c5_hypercube8d": dict(scene="hypercube", dims=8, res=(24, 14), depth=128, fb=True, kat=128),
+    # tests/scenes/parity_zoo.c (this repo's own scene program, compiled against the reference):
+    # spot light, LIGHT_AMBIENT entry + scn->ambient, glass with total internal reflection, finite
+    # hcylinder, infinite cylinder, computed-normal hfacet, skewed hcube, rotated cluster
+    "zoo4d": dict(scene="parity_zoo", dims=4, res=(96, 54), depth=6, fb=True, kat=2048),
+    "zoo3d_mirror": dict(scene="parity_zoo", dims=3, res=(64, 48), depth=128, fb=True, kat=512, config="mirror"),
+    "zoo5d_f2": dict(scene="parity_zoo", dims=5, res=(48, 27), depth=8, fb=True, kat=512, frame=2),
+    "zoo6d": dict(scene="parity_zoo", dims=6, res=(40, 24), depth=5, fb=True, kat=256),
     # an animated frame: rotated hypercube, different tree
     "c1_hypercube3d_f37": dict(scene="hypercube", dims=3, res=(64, 64), depth=128, fb=True, kat=0, frame=37),
     # full BASELINE resolution, 8-bit (what the reference writes to PNG)
@@ -122,8 +129,10 @@ def generate(name, case):
     threads = str(os.cpu_count() or 1)
     base = ["--scene", os.path.join(REF, "scenes", case["scene"] + ".so"), "--dims", str(case["dims"]),
             "--frame", str(frame), "--res", "%dx%d" % (w, h), "--threads", threads, "--depth", str(case["depth"])]
+    if case.get("config"):
+        base += ["--config", case["config"]]
     meta = dict(name=name, scene=case["scene"], dims=case["dims"], width=w, height=h, depth=case["depth"],
-                frame=frame, generator="tests/golden/make_golden.py via oracle/ref_shim.c")
+                frame=frame, config=case.get("config"), generator="tests/golden/make_golden.py via oracle/ref_shim.c")
     arrays = {}
     with tempfile.TemporaryDirectory() as tmp:
         scene_txt = os.path.join(tmp, "scene.txt")

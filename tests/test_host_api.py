@@ -23,17 +23,28 @@ DRIVER = os.path.join(HOST, "ndt_hip")
 REF_SRC = "/root/reference/scenes"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "scenes")
 
-# fixture -> (scene program, dims, frame)
+# fixture -> (scene program, dims, frame, config)
 CASES = {
-    "c1_hypercube3d": ("hypercube", 3, 0),
-    "c1_hypercube3d_f37": ("hypercube", 3, 37),
-    "c2_balls4d": ("balls", 4, 0),
-    "c3_random4d": ("random", 4, 0),
-    "c5_hypercube4d": ("hypercube", 4, 0),
-    "c5_hypercube5d": ("hypercube", 5, 0),
-    "c5_hypercube6d": ("hypercube", 6, 0),
-    "c5_hypercube7d": ("hypercube", 7, 0),
+    "c1_hypercube3d": ("hypercube", 3, 0, None),
+    "c1_hypercube3d_f37": ("hypercube", 3, 37, None),
+    "c2_balls4d": ("balls", 4, 0, None),
+    "c3_random4d": ("random", 4, 0, None),
+    "c5_hypercube4d": ("hypercube", 4, 0, None),
+    "c5_hypercube5d": ("hypercube", 5, 0, None),
+    "c5_hypercube6d": ("hypercube", 6, 0, None),
+    "c5_hypercube7d": ("hypercube", 7, 0, None),
+    # this repository's own scene program (tests/scenes/parity_zoo.c)
+    "zoo4d": ("parity_zoo", 4, 0, None),
+    "zoo3d_mirror": ("parity_zoo", 3, 0, "mirror"),
+    "zoo5d_f2": ("parity_zoo", 5, 2, None),
+    "zoo6d": ("parity_zoo", 6, 0, None),
 }
+OWN_SRC = os.path.join(ROOT, "tests", "scenes")
+
+
+def _source_of(prog):
+    own = os.path.join(OWN_SRC, prog + ".c")
+    return own if os.path.exists(own) else os.path.join(REF_SRC, prog + ".c")
 
 
 @pytest.fixture(scope="module")
@@ -49,50 +60,55 @@ def _fixture_text(name):
         return f.read()
 
 
-def _dump(driver, scene_so, dims, frame, out):
-    r = subprocess.run([driver, "-s", scene_so, "-d", str(dims), "-f", "%d:%d" % (frame, frame), "--dump-scene", out],
-                       capture_output=True, text=True, cwd=os.path.dirname(out))
+def _dump(driver, scene_so, dims, frame, out, config=None):
+    cmd = [driver, "-s", scene_so, "-d", str(dims), "-f", "%d:%d" % (frame, frame), "--dump-scene", out]
+    if config:
+        cmd += ["-u", config]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(out))
     assert r.returncode == 0, r.stderr[-2000:]
     with open(out) as f:
         return f.read()
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference sources only exist in the build container")
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_scene_sources_compile_unchanged_and_flatten_identically(driver, tmp_path, name):
-    prog, dims, frame = CASES[name]
+    prog, dims, frame, config = CASES[name]
+    if not os.path.exists(_source_of(prog)):
+        pytest.skip("reference sources only exist in the build container")
     # scenes say #include "../scene.h": lay the tree out so that resolves to our headers
     (tmp_path / "scenes").mkdir()
     for h in os.listdir(os.path.join(HOST, "include")):
         os.symlink(os.path.join(HOST, "include", h), tmp_path / h)
-    os.symlink(os.path.join(REF_SRC, prog + ".c"), tmp_path / "scenes" / (prog + ".c"))
+    os.symlink(_source_of(prog), tmp_path / "scenes" / (prog + ".c"))
     so = str(tmp_path / "scenes" / (prog + ".so"))
     r = subprocess.run(["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-fPIC", "-shared", "-Wall", "-o", so,
                         str(tmp_path / "scenes" / (prog + ".c"))], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene")) == _fixture_text(name)
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config) == _fixture_text(name)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built (make -C oracle ref)")
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_built_scene_binaries_load_unchanged(driver, tmp_path, name):
-    prog, dims, frame = CASES[name]
+    prog, dims, frame, config = CASES[name]
     so = os.path.join(REF_BIN, prog + ".so")
-    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene")) == _fixture_text(name)
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config) == _fixture_text(name)
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
-@pytest.mark.parametrize("name", ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube6d"])
+@pytest.mark.parametrize("name", ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube6d", "zoo4d", "zoo3d_mirror"])
 def test_end_to_end_reference_scene_to_pixels(driver, tmp_path, name):
     """The whole drop-in: the reference's scene binary -> our host API -> flatten -> GPU ->
     the framebuffer the compiled reference rendered."""
-    prog, dims, frame = CASES[name]
+    prog, dims, frame, config = CASES[name]
     g = golden(name)
     raw = str(tmp_path / "fb.f64")
-    r = subprocess.run([driver, "-s", os.path.join(REF_BIN, prog + ".so"), "-d", str(dims), "-f", "0",
-                        "-r", "%dx%d" % (g.width, g.height), "-l", str(g.depth), "--raw", raw],
-                       capture_output=True, text=True, cwd=str(tmp_path))
+    cmd = [driver, "-s", os.path.join(REF_BIN, prog + ".so"), "-d", str(dims), "-f", "0",
+           "-r", "%dx%d" % (g.width, g.height), "-l", str(g.depth), "--raw", raw]
+    if config:
+        cmd += ["-u", config]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     fb = np.fromfile(raw).reshape(g.height, g.width, 4)
     assert np.abs(fb - g.data["fb"]).max() < 1e-9
