@@ -699,16 +699,19 @@ template <int MW> struct VisitMask {
         ph_last = now_;                                                   \
     } while (0)
 #define NDT_COUNT(slot) (cnt[slot] += 1)
+/* wave-level occupancy of a loop body: iterations and active lanes (same value in every active lane) */
+#define NDT_OCC(slot) do { occ[2 * (slot)] += 1; occ[2 * (slot) + 1] += __popcll(__ballot(1)); } while (0)
 #else
 #define NDT_STAMP(slot) do { } while (0)
 #define NDT_COUNT(slot) do { } while (0)
+#define NDT_OCC(slot) do { } while (0)
 #endif
 
 template <int N, int MW>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
-                      , unsigned long long (&ph)[4], unsigned int (&cnt)[8]
+                      , unsigned long long (&ph)[4], unsigned int (&cnt)[8], unsigned int (&occ)[8]
 #endif
                       )
 {
@@ -809,6 +812,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             }
         }
         while (!have_list && !done) {
+            NDT_OCC(0);
             bool visit = have_node;
             if (!have_node) {
                 if (sp == 0) {
@@ -888,6 +892,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             int prim = -1;
             bool scanning = true;
             while (scanning) {
+                NDT_OCC(1);
                 if (in_sub && sub_i == sub_end) {
                     // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
                     // then the outer trace() applies its accept / break rules
@@ -937,6 +942,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 list_open = false;
             } else {
                 // ---- phase I: intersect
+                NDT_OCC(2);
                 double res[N], nrm[N];
                 const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
                 if (ok) {

@@ -919,11 +919,17 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             if (hc[2] != 0) { overflow = hc[2]; break; }
             for (int k = 0; k < n_seg; ++k) shadow_total += hc[16 + k];
             if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
-                unsigned long long d[16];
+                unsigned long long d[32];
                 if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
                     fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[4]);
                     fprintf(stderr, "ndt_hip: cumulative per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
                             d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
+                    for (int kind = 0; kind < 2; ++kind) {
+                        const unsigned long long *q = d + 16 + 8 * kind;
+                        fprintf(stderr, "ndt_hip: cumulative loop occupancy (%s launches): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
+                                kind ? "shadow" : "closest", q[0] ? 100.0 * q[1] / (64.0 * q[0]) : 0.0, q[0],
+                                q[2] ? 100.0 * q[3] / (64.0 * q[2]) : 0.0, q[2], q[4] ? 100.0 * q[5] / (64.0 * q[4]) : 0.0, q[4]);
+                    }
                 }
                 long long sh = 0;
                 for (int k = 0; k < n_seg; ++k) sh += hc[16 + k];

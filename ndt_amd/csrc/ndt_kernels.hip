@@ -205,7 +205,14 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         int obj, prim;
 #ifdef NDT_PHASE_TIMING
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt);
+        unsigned int occ[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ);
+        if (ws.dbg) {
+            // every active lane holds the same per-wave numbers: let the lowest active lane report
+            const unsigned long long act = __ballot(1);
+            if (lane == __ffsll((long long)act) - 1)
+                for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[16 + 8 * (int)(job.n_seg > 0) + i], (unsigned long long)occ[i]);
+        }
         if (ws.dbg) {
             for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[8 + i], (unsigned long long)cnt[i]);
             atomicAdd(&ws.dbg[14], 1ull);
