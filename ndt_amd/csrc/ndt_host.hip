@@ -862,13 +862,13 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         long long shadow_total = 0;
         int overflow = 0;
         int launches = 0;
-        while (lr.count > 0) {
-            levels.push_back(lr);
-            // closest-hit queries of this bounce
+        // closest-hit queries of the primaries: the only launch that is not shared
+        {
             TraceJob tj{};
-            tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = nullptr; tj.valid = ws.depth_left; tj.n_seg = 0;
-            tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = lr.begin; tj.count = lr.count;
-            if (queue_slot + 2 > NDT_QUEUE_SLOTS) return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS / 2);
+            tj.n_seg = 0;
+            tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
+            tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
+            tj.begin = 0; tj.count = rg.n_primary; tj.tail_ptr = nullptr;
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
@@ -876,11 +876,15 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
                 HIP_TRY(hipEventRecord(b2, s));
                 trace_ev.push_back({ a, b2 });
-                trace_dbg.push_back("closest, bounce " + std::to_string(levels.size() - 1) + ", " + std::to_string(lr.count) + " nodes");
+                trace_dbg.push_back("closest 0: " + std::to_string(rg.n_primary) + " rays");
             } else {
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
             }
             ++launches;
+        }
+        while (lr.count > 0) {
+            levels.push_back(lr);
+            if (queue_slot + 1 > NDT_QUEUE_SLOTS) return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
             // shadow queue: one segment per non-ambient light, each able to hold the whole bounce
             const int n_seg = ctx->n_shadow_lights;
             lr.seg_stride = (lr.count + 63) & ~63LL;
@@ -891,23 +895,32 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             }
             levels.back() = lr;
             HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_SEG, 0, 64 * sizeof(int), s));
+            // hit points, shadow rays of this bounce, and the rays of the next bounce
             kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, lr);
-            if (n_seg > 0) {
-                TraceJob sj{};
-                sj.o = ws.so; sj.v = ws.sv; sj.stride = ws.sh_cap; sj.lim = ws.slim; sj.valid = nullptr;
-                sj.seg_count = ws.counters + NDT_CNT_SEG; sj.seg_stride = lr.seg_stride; sj.n_seg = n_seg;
-                sj.out_obj = ws.sobj; sj.out_prim = ws.sprim; sj.begin = 0;
-                sj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
-                sj.count = lr.count * n_seg;        // upper bound, sizes the grid only
+            const long long next_begin = lr.begin + lr.count;
+            {
+                // ONE launch: shadow rays of bounce b + closest-hit rays of bounce b+1
+                TraceJob tj{};
+                tj.n_seg = n_seg;
+                tj.seg.o = ws.so; tj.seg.v = ws.sv; tj.seg.stride = ws.sh_cap; tj.seg.lim = ws.slim; tj.seg.valid = nullptr;
+                tj.seg.out_obj = ws.sobj; tj.seg.out_prim = ws.sprim;
+                tj.seg_count = ws.counters + NDT_CNT_SEG; tj.seg_stride = lr.seg_stride;
+                tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
+                tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
+                tj.begin = next_begin;
+                tj.count = 2 * lr.count;                        // at most two children per node
+                if (tj.count > ws.cap - next_begin) tj.count = ws.cap - next_begin;
+                tj.tail_ptr = ws.counters;                      // node pool tail, advanced by shade_emit
+                tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
                 if (prof) {
                     hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                     HIP_TRY(hipEventRecord(a, s));
-                    kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
+                    kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
                     HIP_TRY(hipEventRecord(b2, s));
                     trace_ev.push_back({ a, b2 });
-                    trace_dbg.push_back("shadow, bounce " + std::to_string(levels.size() - 1));
+                    trace_dbg.push_back("shadow " + std::to_string(levels.size() - 1) + " + closest " + std::to_string(levels.size()));
                 } else {
-                    kt->trace(s, ctx->d_blob, ctx->sd, ws, sj, ctx->tier, ctx->sd.mask_words);
+                    kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
                 }
                 ++launches;
             }
@@ -926,7 +939,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                             d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
                     for (int kind = 0; kind < 2; ++kind) {
                         const unsigned long long *q = d + 16 + 8 * kind;
-                        fprintf(stderr, "ndt_hip: cumulative loop occupancy (%s launches): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
+                        fprintf(stderr, "ndt_hip: cumulative loop occupancy (%s rays): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
                                 kind ? "shadow" : "closest", q[0] ? 100.0 * q[1] / (64.0 * q[0]) : 0.0, q[0],
                                 q[2] ? 100.0 * q[3] / (64.0 * q[2]) : 0.0, q[2], q[4] ? 100.0 * q[5] / (64.0 * q[4]) : 0.0, q[4]);
                     }
@@ -935,7 +948,6 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 for (int k = 0; k < n_seg; ++k) sh += hc[16 + k];
                 fprintf(stderr, "ndt_hip: bounce %zu: %lld nodes, %lld shadow rays\n", levels.size() - 1, lr.count, sh);
             }
-            const long long next_begin = lr.begin + lr.count;
             lr.begin = next_begin;
             lr.count = (long long)hc[0] - next_begin;
         }
@@ -1053,8 +1065,9 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     }
     HIP_TRY(hipMemcpyAsync(ws.frac, dist_limit, cnt * sizeof(double), hipMemcpyHostToDevice, s));
     TraceJob tj{};
-    tj.o = ws.ray_o; tj.v = ws.ray_v; tj.stride = ws.cap; tj.lim = ws.frac; tj.valid = nullptr; tj.n_seg = 0;
-    tj.out_obj = ws.hit_obj; tj.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt;
+    tj.n_seg = 0;
+    tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = ws.frac; tj.dense.valid = nullptr;
+    tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.tail_ptr = nullptr;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);

@@ -145,17 +145,19 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     // there are idle CUs to run them); for a segmented queue every segment is padded to whole batches
     const int bs = job.batch;
     const int sh = (bs == 64) ? 6 : (bs == 32) ? 5 : (bs == 16) ? 4 : 3;
-    long long n_batches;
-    int seg_batches_incl = 0, seg_cnt = 0;      // lane s: inclusive prefix of batches / count of segment s
+    int seg_batches = 0, seg_batches_incl = 0, seg_cnt = 0;     // lane s: inclusive prefix of batches / count of segment s
     if (job.n_seg > 0) {
         seg_cnt = (lane < job.n_seg) ? job.seg_count[lane] : 0;
-        int total;
-        const int excl = wave_excl_scan((seg_cnt + bs - 1) >> sh, total);
+        const int excl = wave_excl_scan((seg_cnt + bs - 1) >> sh, seg_batches);
         seg_batches_incl = excl + ((seg_cnt + bs - 1) >> sh);
-        n_batches = total;
-    } else {
-        n_batches = (job.count + bs - 1) >> sh;
     }
+    long long dense_count = job.count;
+    if (job.tail_ptr) {
+        const long long live = (long long)*job.tail_ptr - job.begin;    // produced earlier on this stream
+        dense_count = live < 0 ? 0 : (live < dense_count ? live : dense_count);
+        if (job.tail_ptr[2] != 0) dense_count = 0;      // pool overflow: the host retries with a larger pool
+    }
+    const long long n_batches = seg_batches + ((dense_count + bs - 1) >> sh);
     // The batches are split into NDT_QUEUE_SHARDS contiguous shards, each with its own head on
     // its own cache line: a single head word saturates near 90 pops/us on MI355X, which a
     // 32k-batch launch would feel.  A wavefront drains its home shard (workgroup id mod shards,
@@ -184,7 +186,8 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         }
         if (b < 0) break;
         long long g;
-        if (job.n_seg > 0) {
+        const bool in_seg = b < seg_batches;            // wave-uniform
+        if (in_seg) {
             // segment of batch b = number of segments whose inclusive prefix is <= b
             const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= (int)b));
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
@@ -193,15 +196,16 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             if (lane >= bs || idx >= cnt) continue;
             g = (long long)s * job.seg_stride + idx;
         } else {
-            const long long r = (long long)b * bs + lane;
-            if (lane >= bs || r >= job.count) continue;
+            const long long r = (b - seg_batches) * bs + lane;
+            if (lane >= bs || r >= dense_count) continue;
             g = job.begin + r;
-            if (job.valid && job.valid[g] <= 0) continue;
+            if (job.dense.valid && job.dense.valid[g] <= 0) continue;
         }
+        const TracePart &part = in_seg ? job.seg : job.dense;
         double o[N], v[N];
-        load_soa<N>(job.o, job.stride, g, o);
-        load_soa<N>(job.v, job.stride, g, v);
-        const double lim = job.lim ? job.lim[g] : -1.0;
+        load_soa<N>(part.o, part.stride, g, o);
+        load_soa<N>(part.v, part.stride, g, v);
+        const double lim = part.lim ? part.lim[g] : -1.0;
         int obj, prim;
 #ifdef NDT_PHASE_TIMING
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             // every active lane holds the same per-wave numbers: let the lowest active lane report
             const unsigned long long act = __ballot(1);
             if (lane == __ffsll((long long)act) - 1)
-                for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[16 + 8 * (int)(job.n_seg > 0) + i], (unsigned long long)occ[i]);
+                for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[16 + 8 * (int)in_seg + i], (unsigned long long)occ[i]);
         }
         if (ws.dbg) {
             for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[8 + i], (unsigned long long)cnt[i]);
@@ -220,8 +224,8 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
 #else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
 #endif
-        job.out_obj[g] = obj;
-        job.out_prim[g] = prim;
+        part.out_obj[g] = obj;
+        part.out_prim[g] = prim;
     }
 #ifdef NDT_PHASE_TIMING
     if (lane == 0 && ws.dbg) {
@@ -252,12 +256,13 @@ template <typename K> static int resident_blocks(K kernel, int block, size_t lds
 static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, TraceJob job, int tier,
                          int mask_words)
 {
-    if (job.count <= 0) return;
+    if (job.count <= 0 && job.n_seg <= 0) return;
     static const int block = env_int("NDT_TRACE_BLOCK", NDT_TRACE_BLOCK);
     static const int force_batch = env_int("NDT_TRACE_BATCH", 0);
     job.batch = 64;
     if (force_batch == 64 || force_batch == 32 || force_batch == 16 || force_batch == 8) job.batch = force_batch;
-    long long blocks = (job.count + job.batch * (block / 64) - 1) / (job.batch * (block / 64));
+    const long long upper = job.count + (job.n_seg > 0 ? job.seg_stride * job.n_seg : 0);      // sizes the grid only
+    long long blocks = (upper + job.batch * (block / 64) - 1) / (job.batch * (block / 64));
     if (tier == 0) {
         static const int extra_lds = env_int("NDT_TRACE_EXTRA_LDS", 0);   // experiment knob: lowers occupancy
         const size_t lds = (size_t)sd.trace_words * sizeof(double) + (size_t)extra_lds;
@@ -425,6 +430,81 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
         }
         ++seg;
     }
+
+    // get_ray_color, ndt.c:381-430: spawn reflection / refraction.  The children depend on the
+    // hit only, not on the lighting, so they are created here -- before the shadow rays of this
+    // bounce are traced -- and the host traces them in the SAME launch as those shadow rays.
+    bool want_refl = false, want_refr = false;
+    double refl_ray[N], refr_ray[N];
+    double refl_frac = 0, refr_frac = 0;
+    int depth_next = 0;
+    if (shaded) {
+        const int mw = sd.off_mat + 8 * obj;
+        const double refl_r = blob[mw + 3], refl_g = blob[mw + 4], refl_b = blob[mw + 5];
+        const bool transparent = blob[mw + 7] != 0.0;
+        const double frac = ws.frac[g];
+        depth_next = ws.depth_left[g] - 1;
+        const double gb2 = (refl_g > refl_b) ? refl_g : refl_b;
+        const double contrib = (refl_r > gb2) ? refl_r : gb2;
+        int c_refl = -1, c_refr = -1;
+        if (contrib > 0 && (refl_r != 0.0 || refl_g != 0.0 || refl_b != 0.0)) {
+            refl_frac = contrib * frac;
+            // child cut-offs (ndt.c:336-341) return black without tracing
+            if (refl_frac < (1.0 / 512.0) || depth_next <= 0) {
+                c_refl = -2;
+            } else {
+                v_reflect<N>(look, nrm, refl_ray, 1.0);
+                v_unitize<N>(refl_ray);
+                want_refl = true;
+            }
+        }
+        if (transparent) {
+            refr_frac = (1 - contrib) * frac;
+            if (refr_frac < (1.0 / 512.0) || depth_next <= 0) {
+                c_refr = -2;
+            } else {
+                v_refract<N>(look, nrm, refr_ray, blob[mw + 6]);    // unitizes nrm; nothing reads it afterwards
+                v_unitize<N>(refr_ray);
+                want_refr = true;
+            }
+        }
+        ws.child_refl[g] = c_refl;
+        ws.child_refr[g] = c_refr;
+    }
+    // Compact the children of this wavefront into the next bounce: one reservation per
+    // wavefront, reflection rays first and refraction rays after them.
+    const unsigned long long v_refl = __ballot(want_refl), v_refr = __ballot(want_refr);
+    const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
+    const int base = wave_reserve(&ws.counters[0], total);
+    if (total > 0 && (long long)base + total > ws.cap) {
+        if (lane == 0) atomicOr(&ws.counters[2], 1);
+        return;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (want_refl) {
+        const long long c = (long long)base + __popcll(v_refl & below);
+        store_soa<N>(ws.ray_o, ws.cap, c, hit);
+        store_soa<N>(ws.ray_v, ws.cap, c, refl_ray);
+        ws.frac[c] = refl_frac;
+        ws.depth_left[c] = depth_next;
+        ws.child_refl[c] = -1;
+        ws.child_refr[c] = -1;
+        ws.count[c] = 0;
+        ws.sh_mask[c] = 0ull;
+        ws.child_refl[g] = (int)c;
+    }
+    if (want_refr) {
+        const long long c = (long long)base + n_refl + __popcll(v_refr & below);
+        store_soa<N>(ws.ray_o, ws.cap, c, hit);
+        store_soa<N>(ws.ray_v, ws.cap, c, refr_ray);
+        ws.frac[c] = refr_frac;
+        ws.depth_left[c] = depth_next;
+        ws.child_refl[c] = -1;
+        ws.child_refr[c] = -1;
+        ws.count[c] = 0;
+        ws.sh_mask[c] = 0ull;
+        ws.child_refr[g] = (int)c;
+    }
 }
 
 // ------------------------------------------------------------------ shading, second half
@@ -439,12 +519,8 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
     if (in_range && ws.depth_left[g] > 0) obj = ws.hit_obj[g];
     const bool shaded = obj >= 0;
 
-    bool want_refl = false, want_refr = false;
-    double refl_ray[N], refr_ray[N], hit[N];
-    double refl_frac = 0, refr_frac = 0;
-    int depth_next = 0;
     if (shaded) {
-        double src[N], look[N], nrm[N];
+        double src[N], look[N], nrm[N], hit[N];
         load_soa<N>(ws.ray_o, ws.cap, g, src);
         load_soa<N>(ws.ray_v, ws.cap, g, look);
         load_soa<N>(ws.hit_p, ws.cap, g, hit);
@@ -523,72 +599,6 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
         ws.clr[2 * ws.cap + g] = cb;
         ws.count[g] = 1 + n_shadow;
 
-        // get_ray_color, ndt.c:381-430: spawn reflection / refraction
-        const double frac = ws.frac[g];
-        depth_next = ws.depth_left[g] - 1;
-        const double gb2 = (refl_g > refl_b) ? refl_g : refl_b;
-        const double contrib = (refl_r > gb2) ? refl_r : gb2;
-        int c_refl = -1, c_refr = -1;
-        if (contrib > 0 && (refl_r != 0.0 || refl_g != 0.0 || refl_b != 0.0)) {
-            refl_frac = contrib * frac;
-            // child cut-offs (ndt.c:336-341) return black without tracing
-            if (refl_frac < (1.0 / 512.0) || depth_next <= 0) {
-                c_refl = -2;
-            } else {
-                v_reflect<N>(look, nrm, refl_ray, 1.0);
-                v_unitize<N>(refl_ray);
-                want_refl = true;
-            }
-        }
-        if (transparent) {
-            refr_frac = (1 - contrib) * frac;
-            if (refr_frac < (1.0 / 512.0) || depth_next <= 0) {
-                c_refr = -2;
-            } else {
-                v_refract<N>(look, nrm, refr_ray, blob[mw + 6]);
-                v_unitize<N>(refr_ray);
-                want_refr = true;
-            }
-        }
-        ws.child_refl[g] = c_refl;
-        ws.child_refr[g] = c_refr;
-    }
-    // Compact the children of this wavefront into the next bounce: one reservation per
-    // wavefront, reflection rays first and refraction rays after them, so that the wavefronts
-    // of the next bounce hold one kind of ray (the two kinds leave a surface in unrelated
-    // directions and would diverge from the first tree node on).
-    const int lane = __lane_id();
-    const unsigned long long v_refl = __ballot(want_refl), v_refr = __ballot(want_refr);
-    const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
-    const int base = wave_reserve(&ws.counters[0], total);
-    if (total > 0 && (long long)base + total > ws.cap) {
-        if (lane == 0) atomicOr(&ws.counters[2], 1);
-        return;
-    }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (want_refl) {
-        const long long c = (long long)base + __popcll(v_refl & below);
-        store_soa<N>(ws.ray_o, ws.cap, c, hit);
-        store_soa<N>(ws.ray_v, ws.cap, c, refl_ray);
-        ws.frac[c] = refl_frac;
-        ws.depth_left[c] = depth_next;
-        ws.child_refl[c] = -1;
-        ws.child_refr[c] = -1;
-        ws.count[c] = 0;
-        ws.sh_mask[c] = 0ull;
-        ws.child_refl[g] = (int)c;
-    }
-    if (want_refr) {
-        const long long c = (long long)base + n_refl + __popcll(v_refr & below);
-        store_soa<N>(ws.ray_o, ws.cap, c, hit);
-        store_soa<N>(ws.ray_v, ws.cap, c, refr_ray);
-        ws.frac[c] = refr_frac;
-        ws.depth_left[c] = depth_next;
-        ws.child_refl[c] = -1;
-        ws.child_refr[c] = -1;
-        ws.count[c] = 0;
-        ws.sh_mask[c] = 0ull;
-        ws.child_refr[g] = (int)c;
     }
 }
 

@@ -45,21 +45,32 @@ struct RenderGeom {
     int specular;
 };
 
-struct TraceJob {
+// One k_trace launch = up to two parts, served from one work queue:
+//   seg   : a segmented queue (shadow rays of bounce b, one segment per light so that a
+//           wavefront's rays share their origin): segment s holds seg_count[s] rays at
+//           [s*seg_stride, ...), each with its own dist_limit;
+//   dense : one range [begin, begin+count) of closest-hit queries (the nodes of bounce b+1, or
+//           the batch of the trace_rays API).  count may live on the device (tail_ptr).
+// Shadow rays of one bounce and the closest-hit rays of the next are independent, so the host
+// puts them in the same launch: every launch has a latency floor of one incoherent batch
+// (~0.3 ms on the benchmark scene), and this halves the number of floors per frame.
+struct TracePart {
     const double *o, *v;        // [N][stride]
     long long stride;
     const double *lim;          // per-ray dist_limit, or nullptr => -1 (closest hit)
     const int *valid;           // depth_left, or nullptr => all valid
-    // segmented queue (shadow rays, one segment per light so that a wavefront's rays share
-    // their origin): segment s holds seg_count[s] rays at [s*seg_stride, ...); n_seg == 0 => one
-    // dense range [begin, begin+count)
+    int *out_obj, *out_prim;
+};
+struct TraceJob {
+    TracePart seg;
     const int *seg_count;
     long long seg_stride;
-    int n_seg;
-    int *queue;                 // device-side work-queue head for this launch (zeroed by the host)
+    int n_seg;                  // 0 => no segmented part
+    TracePart dense;
+    long long begin, count;     // dense range; count is an upper bound when tail_ptr is set
+    const int *tail_ptr;        // device word holding the end of the dense range (node pool tail), or nullptr
+    int *queue;                 // device-side work-queue heads for this launch (zeroed by the host)
     int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
-    int *out_obj, *out_prim;
-    long long begin, count;
 };
 
 struct LevelRange {
