@@ -203,6 +203,14 @@ int ndt_hip_quantize_device(ndt_hip_ctx *ctx, const void *d_rgba, void *d_rgba8,
 /* Number of rows a (row_begin,row_step) shard of a `height`-row image holds. */
 int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step);
 
+/* Diagnostic, host only (no GPU needed): the hull box the library derives for hcube `object`
+ * of `scene` at upload time -- an oriented box that contains every point orthotope.intersect
+ * (orthotope.c:150-300) can return for the hcube's faces; rays that miss it skip the nested
+ * trace() over the faces (hcube.c:241), which cannot change the answer.  rows receives
+ * dims x { unit axis[dims], centre coordinate, half extent }.  Returns 1 when the hcube has a
+ * box, 0 when it has none (its faces are always scanned), <0 on NDT_E_*. */
+int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *rows);
+
 /* The stream the context launches on (a hipStream_t), for callers that time with their own
  * events or order other work against it. */
 void *ndt_hip_stream(ndt_hip_ctx *ctx);

@@ -26,6 +26,7 @@
 #define NDT_F_INF_ENDS    0x200     /* cylinder.c:87 / hcylinder.c:107 */
 #define NDT_F_USE_NORMALS 0x400     /* hfacet.c:283 */
 #define NDT_F_TRANSPARENT 0x800
+#define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_host.hip:hcube_hull_box) */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
 // light_type numbering of the reference, scene.h:23-31
@@ -622,6 +623,33 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
     return true;
 }
 
+// Ray (t >= 0) against the hull box of an hcube: N slabs { axis[N], centre, half extent }.
+// A miss proves that no face of the hcube can be hit (see ndt_host.hip:hcube_hull_box for the
+// margin argument), so the 2N-face scan is skipped; a pass decides nothing.
+template <int N> NDT_DEV bool hull_box_pass(const double *blob, int p, const double (&o)[N], const double (&v)[N])
+{
+    double t0 = 0.0, t1 = NDT_DBL_MAX;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double u[N];
+        blob_vec<N>(blob, p + k * (N + 2), u);
+        const double a = v_dot<N>(u, o) - blob[p + k * (N + 2) + N];
+        const double d = v_dot<N>(u, v);
+        const double h = blob[p + k * (N + 2) + N + 1];
+        if (fabs(d) < 1e-200) {
+            if (fabs(a) > h) ok = false;        // parallel to the slab and outside it
+        } else {
+            const double inv = 1.0 / d;
+            const double ta = (-h - a) * inv, tb = (h - a) * inv;
+            const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            if (lo > t0) t0 = lo;
+            if (hi < t1) t1 = hi;
+        }
+    }
+    return ok && t0 <= t1;
+}
+
 // ------------------------------------------------------------------ trace / kd-tree
 
 // Per-ray visit mask (the reference callocs obj_num bytes per ray, kd-tree.c:600).
@@ -711,7 +739,7 @@ template <int N, int MW>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
-                      , unsigned long long (&ph)[4], unsigned int (&cnt)[8], unsigned int (&occ)[8]
+                      , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
 #endif
                       )
 {
@@ -730,6 +758,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             r = 1.0 / v_i;
         v_inv[i] = r;
     }
+    NDT_STAMP(5);
 
     // results
     double t_inf = NDT_DBL_MAX;             // `t` of kd_tree_intersect, kd-tree.c:593
@@ -921,13 +950,16 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
                         if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, id, o, v, gate_min)) {
                             if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
-                                // composites only occur in outer lists (validated at upload)
+                              // composites only occur in outer lists (validated at upload)
+                              if (!(flags & NDT_F_BOX) ||
+                                  hull_box_pass<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1), o, v)) {
                                 in_sub = true;
                                 sub_owner = id;
                                 sub_i = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
                                 sub_end = sub_i + blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
                                 sub_min = -1;
                                 sub_prim = -1;
+                              }
                             } else {
                                 prim = id;
                                 scanning = false;

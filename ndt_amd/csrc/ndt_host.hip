@@ -38,6 +38,27 @@ static int fail(int code, const char *fmt, ...)
 
 extern "C" const char *ndt_hip_last_error(void) { return g_err; }
 extern "C" int ndt_hip_abi_version(void) { return NDT_HIP_ABI_VERSION; }
+static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows);
+
+extern "C" int ndt_hip_hcube_hull_box(const ndt_flat_scene *fs, int32_t object, double *rows_out)
+{
+    if (!fs || !rows_out) return fail(NDT_E_INVALID, "null argument");
+    if (fs->abi_version != NDT_HIP_ABI_VERSION) return fail(NDT_E_INVALID, "flat scene ABI %d, library %d", fs->abi_version, NDT_HIP_ABI_VERSION);
+    if (fs->dims < 3 || fs->dims > NDT_MAX_DIMS) return fail(NDT_E_UNSUPPORTED, "dims %d", fs->dims);
+    if (object < 0 || object >= fs->n_objects || fs->objects[object].type != NDT_OBJ_HCUBE)
+        return fail(NDT_E_INVALID, "object %d is not an hcube", object);
+    const ndt_flat_object &o = fs->objects[object];
+    if (o.n_obj < 1 || o.obj_off < 0 || (int64_t)o.obj_off + o.n_obj > fs->n_obj_refs) return fail(NDT_E_INVALID, "object %d: child range", object);
+    for (int k = 0; k < o.n_obj; ++k) {
+        const int c = fs->obj_refs[o.obj_off + k];
+        if (c < 0 || c >= fs->n_objects) return fail(NDT_E_INVALID, "object %d: bad nested primitive %d", object, c);
+    }
+    std::vector<double> rows;
+    if (!hcube_hull_box(fs, o, fs->dims, rows)) return 0;
+    memcpy(rows_out, rows.data(), rows.size() * sizeof(double));
+    return 1;
+}
+
 extern "C" int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step)
 {
     if (row_step < 1 || row_begin < 0 || row_begin >= height) return 0;
@@ -269,6 +290,233 @@ static int kd_preorder(const ndt_flat_scene *fs, int node, int depth, std::vecto
     return NDT_OK;
 }
 
+// Hull box of an hcube: an oriented box that contains every point the faces' intersect() can
+// return.  NOT part of the reference's algorithm -- an exactness-preserving cull, like the
+// kd-tree itself: a ray that misses the box cannot hit any face in the reference's own
+// arithmetic, so trace() over the faces (hcube.c:241) returns "no hit", which is what the device
+// gets by not scanning them.
+//
+// What orthotope.intersect (orthotope.c:150-300) accepts, with y = X - pos, unit basis columns
+// B = [b_1..b_m] and A = B B^T:  |(A - I) y|^2 <= 2*EPSILON  (the `qc -= EPSILON` roots give
+// exactly EPSILON, the closest-approach branch |dist| <= EPSILON) and, within_orthotope
+// (orthotope.c:126-148),  -EPSILON <= y.b_i <= |dir_i| + EPSILON.  Split y = y_par + y_perp
+// (span of B and its complement): |(A-I)y|^2 = |(A-I)y_par|^2 + |y_perp|^2.  In the orthonormal
+// eigenvectors e_j = B w_j / sqrt(l_j) of A on span(B) (G = B^T B = W diag(l) W^T), with
+// alpha_j = y.e_j:   |alpha_j| <= d/|l_j - 1|   and   alpha_j = (w_j . c)/sqrt(l_j) for the slab
+// coordinates c_i = y.b_i in [-EPSILON, |dir_i|+EPSILON];  |y_perp| <= d;  d = sqrt(2*EPSILON).
+// For an orthogonal face (the usual hypercube) l_j = 1 and this is the face grown by EPSILON;
+// for the skewed bases scenes/random.c hands to hcube it is a small blob around pos.
+// The hcube's box is the bounding box, in one orthonormal frame, of the alpha-box corners of
+// all faces, grown by NDT_HULL_MARGIN = 0.02 > d = 0.01415 (y_perp, rounding).
+// rows: N x { unit axis[N], centre coordinate, half extent }.
+#define NDT_HULL_MARGIN 0.02
+#define NDT_HULL_DELTA 0.01485      /* sqrt(2e-4) * 1.05 */
+#define NDT_HULL_EPS 1.1e-4
+
+// cyclic Jacobi: a (m x m, symmetric, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of w
+static void jacobi_eig(std::vector<double> &a, std::vector<double> &w, int m)
+{
+    w.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) w[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) off += a[(size_t)i * m + j] * a[(size_t)i * m + j];
+        if (off < 1e-26) break;
+        for (int pi = 0; pi < m; ++pi)
+            for (int q = pi + 1; q < m; ++q) {
+                const double apq = a[(size_t)pi * m + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (a[(size_t)q * m + q] - a[(size_t)pi * m + pi]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < m; ++k) {       // columns
+                    const double akp = a[(size_t)k * m + pi], akq = a[(size_t)k * m + q];
+                    a[(size_t)k * m + pi] = c * akp - sn * akq;
+                    a[(size_t)k * m + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < m; ++k) {       // rows
+                    const double apk = a[(size_t)pi * m + k], aqk = a[(size_t)q * m + k];
+                    a[(size_t)pi * m + k] = c * apk - sn * aqk;
+                    a[(size_t)q * m + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double wkp = w[(size_t)k * m + pi], wkq = w[(size_t)k * m + q];
+                    w[(size_t)k * m + pi] = c * wkp - sn * wkq;
+                    w[(size_t)k * m + q] = sn * wkp + c * wkq;
+                }
+            }
+    }
+}
+
+// corner points (world coordinates) of a box that contains the in-span part of one face's acceptance region
+static bool face_region_corners(const double *pos, const double *dir, int m, int n, std::vector<double> &pts)
+{
+    if (m == 0) {
+        pts.insert(pts.end(), pos, pos + n);
+        return true;
+    }
+    std::vector<double> bu((size_t)m * n), len((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        len[i] = h_len(dir + i * n, n);
+        if (!(len[i] > 0) || !std::isfinite(len[i])) return false;
+        memcpy(&bu[(size_t)i * n], dir + i * n, n * sizeof(double));
+        h_unitize(&bu[(size_t)i * n], n);       // vectNd_unitize, as orthotope.c:37
+    }
+    std::vector<double> g((size_t)m * m), w;
+    double off = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            double d = 0;
+            for (int q = 0; q < n; ++q) d += bu[(size_t)i * n + q] * bu[(size_t)j * n + q];
+            g[(size_t)i * m + j] = d;
+            if (i != j && fabs(d) > off) off = fabs(d);
+        }
+    if (off < 1e-12) {
+        // orthogonal face: keep its own axes (an eigen-solver may return any rotation of a repeated eigenvalue)
+        w.assign((size_t)m * m, 0.0);
+        for (int i = 0; i < m; ++i) w[(size_t)i * m + i] = 1.0;
+    } else {
+        jacobi_eig(g, w, m);
+    }
+    std::vector<double> e((size_t)m * n), lo((size_t)m), hi((size_t)m);
+    for (int j = 0; j < m; ++j) {
+        const double l = g[(size_t)j * m + j];
+        if (!(l > 1e-10) || !std::isfinite(l)) return false;       // dependent directions
+        const double sl = sqrt(l);
+        double slo = 0, shi = 0;
+        for (int q = 0; q < n; ++q) e[(size_t)j * n + q] = 0;
+        for (int i = 0; i < m; ++i) {
+            const double wij = w[(size_t)i * m + j];
+            for (int q = 0; q < n; ++q) e[(size_t)j * n + q] += bu[(size_t)i * n + q] * wij / sl;
+            const double c0 = -NDT_HULL_EPS * wij, c1 = (len[i] + NDT_HULL_EPS) * wij;
+            slo += (c0 < c1 ? c0 : c1) / sl;
+            shi += (c0 < c1 ? c1 : c0) / sl;
+        }
+        lo[j] = slo;
+        hi[j] = shi;
+        if (fabs(l - 1) > 1e-9) {
+            const double r = NDT_HULL_DELTA / fabs(l - 1);
+            if (-r > lo[j]) lo[j] = -r;
+            if (r < hi[j]) hi[j] = r;
+        }
+        if (lo[j] > hi[j]) return true;     // empty region: this face can never be hit; contributes nothing
+    }
+    for (unsigned bits = 0; bits < (1u << m); ++bits) {
+        std::vector<double> pt(pos, pos + n);
+        for (int j = 0; j < m; ++j) {
+            const double aj = (bits & (1u << j)) ? hi[j] : lo[j];
+            for (int q = 0; q < n; ++q) pt[q] += aj * e[(size_t)j * n + q];
+        }
+        pts.insert(pts.end(), pt.begin(), pt.end());
+    }
+    return true;
+}
+
+static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows)
+{
+    std::vector<double> pts;
+    std::vector<std::vector<double>> axes;      // unit face axes, for the aligned candidate frame
+    for (int k = 0; k < o.n_obj; ++k) {
+        const ndt_flat_object &f = fs->objects[fs->obj_refs[o.obj_off + k]];
+        if (f.type != NDT_OBJ_ORTHOTOPE || f.n_flag < 1 || f.n_pos < 1) return false;
+        if (f.flag_off < 0 || (int64_t)f.flag_off + f.n_flag > fs->n_flags) return false;
+        const int m = fs->flags[f.flag_off];
+        if (m < 0 || m > f.n_dir || m > n || m > 16) return false;
+        if (!vec_ok(fs, f.pos_off, 1) || !vec_ok(fs, f.dir_off, m)) return false;
+        if (!face_region_corners(fs->vecs + f.pos_off, fs->vecs + f.dir_off, m, n, pts)) return false;
+        for (int a = 0; a < m; ++a) {
+            std::vector<double> u(fs->vecs + f.dir_off + a * n, fs->vecs + f.dir_off + (a + 1) * n);
+            h_unitize(u.data(), n);
+            axes.push_back(u);
+        }
+    }
+    const size_t n_pts = pts.size() / n;
+    if (n_pts == 0) return false;
+    for (double x : pts)
+        if (!std::isfinite(x)) return false;
+
+    // candidate orthonormal frames: Gram-Schmidt of the face axes, principal axes of the points, world axes
+    auto complete = [&](std::vector<std::vector<double>> &frame, const std::vector<std::vector<double>> &cands, double keep) {
+        for (const auto &a : cands) {
+            if ((int)frame.size() >= n) break;
+            std::vector<double> r(a);
+            for (const auto &u : frame) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += a[c] * u[c];
+                for (int c = 0; c < n; ++c) r[c] -= d * u[c];
+            }
+            const double l = h_len(r.data(), n);
+            if (l > keep) {
+                for (int c = 0; c < n; ++c) r[c] /= l;
+                frame.push_back(r);
+            }
+        }
+    };
+    std::vector<std::vector<double>> world;
+    for (int j = 0; j < n; ++j) {
+        std::vector<double> e((size_t)n, 0.0);
+        e[j] = 1.0;
+        world.push_back(e);
+    }
+    std::vector<std::vector<std::vector<double>>> frames(3);
+    complete(frames[0], axes, 0.5);
+    {
+        std::vector<double> mean((size_t)n, 0.0), cov((size_t)n * n, 0.0), w;
+        for (size_t i = 0; i < n_pts; ++i)
+            for (int c = 0; c < n; ++c) mean[c] += pts[i * n + c] / (double)n_pts;
+        for (size_t i = 0; i < n_pts; ++i)
+            for (int a = 0; a < n; ++a)
+                for (int c = 0; c < n; ++c) cov[(size_t)a * n + c] += (pts[i * n + a] - mean[a]) * (pts[i * n + c] - mean[c]);
+        jacobi_eig(cov, w, n);
+        std::vector<std::vector<double>> pc;
+        for (int j = 0; j < n; ++j) {
+            std::vector<double> u((size_t)n);
+            for (int c = 0; c < n; ++c) u[c] = w[(size_t)c * n + j];
+            pc.push_back(u);
+        }
+        complete(frames[1], pc, 0.5);
+    }
+    double best_cost = 0;
+    int best = -1;
+    std::vector<double> best_rows;
+    for (int fi = 0; fi < 3; ++fi) {
+        auto &frame = frames[fi];
+        for (double keep = 0.5; (int)frame.size() < n && keep > 1e-4; keep *= 0.5) complete(frame, world, keep);
+        if ((int)frame.size() < n) continue;
+        std::vector<double> cand, half((size_t)n);
+        for (int a = 0; a < n; ++a) {
+            double lo = 1e300, hi = -1e300;
+            for (size_t i = 0; i < n_pts; ++i) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += pts[i * n + c] * frame[a][c];
+                if (d < lo) lo = d;
+                if (d > hi) hi = d;
+            }
+            cand.insert(cand.end(), frame[a].begin(), frame[a].end());
+            cand.push_back(0.5 * (lo + hi));
+            half[a] = 0.5 * (hi - lo) + NDT_HULL_MARGIN;
+            cand.push_back(half[a]);
+        }
+        // what a random ray sees of a box grows with its surface: sum over axes of the product of the other extents
+        double cost = 0;
+        for (int a = 0; a < n; ++a) {
+            double prod = 1;
+            for (int c = 0; c < n; ++c)
+                if (c != a) prod *= half[c];
+            cost += prod;
+        }
+        if (best < 0 || cost < best_cost) {
+            best = fi;
+            best_cost = cost;
+            best_rows = cand;
+        }
+    }
+    if (best < 0) return false;
+    rows = best_rows;
+    return true;
+}
+
 static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
 {
     const int n = fs->dims;
@@ -438,11 +686,18 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             aux1 = m;
             break;
         }
-        case NDT_OBJ_HCUBE:
+        case NDT_OBJ_HCUBE: {
             aux0 = child_first[i];
             aux1 = o.n_obj;
-            b.push(0.0);
+            std::vector<double> rows;
+            if (!getenv("NDT_HIP_NO_HULL_BOX") && hcube_hull_box(fs, o, n, rows)) {
+                flags |= NDT_F_BOX;
+                for (double x : rows) b.push(x);
+            } else {
+                b.push(0.0);
+            }
             break;
+        }
         case NDT_OBJ_HFACET: {      // hfacet.c:43-87 + the ray-invariant dots of get_barycentric (hfacet.c:176-181)
             if ((rc = need(o.n_pos >= 3 && o.n_flag >= 1, "hfacet needs 3 pos, 1 flag"))) return rc;
             if ((rc = need(!flag[0] || o.n_dir >= 3, "hfacet with vertex normals needs 3 dir"))) return rc;
@@ -934,7 +1189,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
                 unsigned long long d[32];
                 if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
-                    fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[4]);
+                    fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
                     fprintf(stderr, "ndt_hip: cumulative per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
                             d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
                     for (int kind = 0; kind < 2; ++kind) {

@@ -138,7 +138,12 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     }
     const int lane = __lane_id();
 #ifdef NDT_PHASE_TIMING
-    unsigned long long ph[4] = { 0, 0, 0, 0 };
+    // diagnostic build: everything is accumulated in registers and flushed once per wavefront at
+    // the end of the kernel, so that the counters' atomics do not sit inside the phases they measure
+    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // T, G, I, list end, -, prologue, outside trace_kd, -
+    unsigned long long acc[24];                                  // [0..6] per-ray counts + rays, [8..13] / [16..21] loop occupancy
+    for (int i = 0; i < 24; ++i) acc[i] = 0ull;
+    unsigned long long out_last = __builtin_readcyclecounter();
 #endif
     // batches of `bs` rays (64, or fewer when the launch has too few rays to fill the chip: a
     // wavefront's time is set by its slowest lane, so half-empty wavefronts finish sooner and
@@ -210,16 +215,16 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
 #ifdef NDT_PHASE_TIMING
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         unsigned int occ[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        ph[6] += __builtin_readcyclecounter() - out_last;
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ);
-        if (ws.dbg) {
-            // every active lane holds the same per-wave numbers: let the lowest active lane report
+        out_last = __builtin_readcyclecounter();
+        {
+            // every active lane holds the same per-wave occupancy numbers: the lowest active lane keeps them
             const unsigned long long act = __ballot(1);
             if (lane == __ffsll((long long)act) - 1)
-                for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[16 + 8 * (int)in_seg + i], (unsigned long long)occ[i]);
-        }
-        if (ws.dbg) {
-            for (int i = 0; i < 6; ++i) atomicAdd(&ws.dbg[8 + i], (unsigned long long)cnt[i]);
-            atomicAdd(&ws.dbg[14], 1ull);
+                for (int i = 0; i < 6; ++i) acc[(in_seg ? 16 : 8) + i] += occ[i];
+            for (int i = 0; i < 6; ++i) acc[i] += cnt[i];
+            acc[6] += 1ull;
         }
 #else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
@@ -228,9 +233,19 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         part.out_prim[g] = prim;
     }
 #ifdef NDT_PHASE_TIMING
-    if (lane == 0 && ws.dbg) {
-        for (int i = 0; i < 4; ++i) atomicAdd(&ws.dbg[i], ph[i]);
-        atomicAdd(&ws.dbg[4], 1ull);
+    ph[6] += __builtin_readcyclecounter() - out_last;
+    if (ws.dbg) {
+        for (int i = 0; i < 24; ++i) {
+            unsigned long long x = acc[i];
+            for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+            if (lane == 0 && x) atomicAdd(&ws.dbg[8 + i], x);
+        }
+        if (lane == 0) {
+            for (int i = 0; i < 4; ++i) atomicAdd(&ws.dbg[i], ph[i]);
+            atomicAdd(&ws.dbg[4], 1ull);
+            atomicAdd(&ws.dbg[5], ph[5]);
+            atomicAdd(&ws.dbg[6], ph[6]);
+        }
     }
 #endif
 }

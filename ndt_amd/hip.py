@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
-    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version",
+    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box",
 ]
 
 
@@ -61,8 +61,24 @@ def load_library():
     lib.ndt_hip_quantize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.ndt_hip_synchronize.argtypes = [C.c_void_p]
     lib.ndt_hip_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.ndt_hip_hcube_hull_box.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     _lib = lib
     return lib
+
+
+def hcube_hull_box(fs, obj):
+    """The hull box libndt_hip derives for hcube `obj` of FlatScene `fs` (host only, no GPU):
+    (axes[N,N], centre[N], half[N]) or None when the hcube gets no box."""
+    import numpy as np
+    lib = load_library()
+    n = fs.dims
+    rows = np.zeros((n, n + 2), dtype=np.float64)
+    rc = lib.ndt_hip_hcube_hull_box(fs.byref(), int(obj), rows.ctypes.data)
+    if rc < 0:
+        raise NdtHipError(rc, (lib.ndt_hip_last_error() or b"").decode())
+    if rc == 0:
+        return None
+    return rows[:, :n].copy(), rows[:, n].copy(), rows[:, n + 1].copy()
 
 
 class NdtHip:

@@ -1,0 +1,122 @@
+"""The hcube hull box (ndt_host.hip:hcube_hull_box, ndt_hip_hcube_hull_box) is the one place
+where the device does LESS than the reference: a ray that misses the box skips the nested
+trace() over the hcube's faces (hcube.c:241).  That is only legitimate if no point the
+reference can return for a face lies outside the box.  Checked here
+  * on the CPU: every hit the oracle reports on an hcube, for rays aimed at its faces, lies
+    inside the box with the slack the derivation promises (margin 0.02 vs reach 0.01485);
+  * on the GPU: the same rays give bit-identical answers with the oracle, and with the box
+    switched off (NDT_HIP_NO_HULL_BOX=1 at upload).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+HCUBE = 6
+SCENES = ["c3_random4d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d"]
+SLACK = 0.02 - 0.01485
+
+
+def hcubes(fs):
+    return [i for i, o in enumerate(fs.objects) if o["type"] == HCUBE and o["parent"] < 0]
+
+
+def aimed_rays(fs, box_of, seed, per_target=6):
+    """Rays aimed at the places where faces can be hit: around every face's position (where the
+    acceptance region of a skewed face sits), over every face's span, and through the box."""
+    rng = np.random.default_rng(seed)
+    n = fs.dims
+    vecs = np.asarray(fs.vecs, dtype=np.float64).ravel()
+    flags = np.asarray(fs.flags)
+    refs = np.asarray(fs.obj_refs)
+    targets = []
+    for h in hcubes(fs):
+        o = fs.objects[h]
+        for k in range(o["n_obj"]):
+            f = fs.objects[refs[o["obj_off"] + k]]
+            m = int(flags[f["flag_off"]])
+            pos = vecs[f["pos_off"]:f["pos_off"] + n]
+            dirs = vecs[f["dir_off"]:f["dir_off"] + m * n].reshape(m, n)
+            for _ in range(per_target):
+                targets.append(pos + rng.normal(0, 0.006, n))
+                targets.append(pos + rng.uniform(0, 1, m) @ dirs + rng.normal(0, 0.004, n))
+        box = box_of(h)
+        if box is not None:
+            ax, c, half = box
+            for _ in range(8 * per_target):
+                targets.append((c + rng.uniform(-1, 1, n) * half) @ ax)
+    targets = np.array(targets)
+    d = rng.normal(0, 1, targets.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = rng.uniform(2.0, 12.0, (len(targets), 1))
+    rays = np.zeros((len(targets), 2 * n + 1))
+    rays[:, :n] = targets - d * dist
+    rays[:, n:2 * n] = d
+    rays[:, 2 * n] = -1.0
+    # a third of them as shadow-style queries (any hit closer than the limit)
+    rays[::3, 2 * n] = dist[::3, 0] * 1.5
+    return rays
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_every_oracle_hit_on_an_hcube_lies_inside_its_hull_box(oracle, name):
+    from ndt_amd.hip import hcube_hull_box
+    fs = golden(name).scene
+    hs = hcubes(fs)
+    if not hs:
+        pytest.skip("no hcube in this scene")
+    boxes = {h: hcube_hull_box(fs, h) for h in hs}
+    assert any(b is not None for b in boxes.values())
+    for b in boxes.values():
+        if b is not None:
+            ax = b[0]
+            assert np.abs(ax @ ax.T - np.eye(fs.dims)).max() < 1e-12      # orthonormal frame
+    rays = aimed_rays(fs, boxes.get, seed=11)
+    obj, hit, _ = oracle.trace(fs, rays)
+    n_hits = 0
+    for h in hs:
+        sel = obj == h
+        n_hits += int(sel.sum())
+        if boxes[h] is None or not sel.any():
+            continue
+        ax, c, half = boxes[h]
+        coord = hit[sel] @ ax.T - c
+        worst = (np.abs(coord) - (half - SLACK)).max()
+        assert worst <= 0, "hcube %d: a reference hit lies %g outside the box interior" % (h, worst)
+    assert n_hits > 15          # the aimed rays do reach the faces (skewed ones of random.c included)
+
+
+def test_hull_box_of_a_non_hcube_is_an_error():
+    from ndt_amd.hip import hcube_hull_box, NdtHipError
+    fs = golden("c3_random4d").scene
+    other = next(i for i, o in enumerate(fs.objects) if o["type"] != HCUBE)
+    with pytest.raises(NdtHipError):
+        hcube_hull_box(fs, other)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_cull_changes_nothing_on_the_device(oracle, name):
+    from ndt_amd.hip import NdtHip, hcube_hull_box
+    fs = golden(name).scene
+    if not hcubes(fs):
+        pytest.skip("no hcube in this scene")
+    rays = aimed_rays(fs, lambda h: hcube_hull_box(fs, h), seed=23, per_target=12)
+    want = oracle.trace(fs, rays)
+    gpu = NdtHip(0)
+    try:
+        gpu.upload_scene(fs)
+        got = gpu.trace_rays(rays)
+        os.environ["NDT_HIP_NO_HULL_BOX"] = "1"
+        try:
+            gpu.upload_scene(fs)
+            plain = gpu.trace_rays(rays)
+        finally:
+            del os.environ["NDT_HIP_NO_HULL_BOX"]
+    finally:
+        gpu.close()
+    for a, b, c in zip(got, plain, want):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)
