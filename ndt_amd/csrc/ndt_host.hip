@@ -874,6 +874,8 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
         return NDT_OK;
     if (cap < ws.cap) cap = ws.cap;
     if (sh_cap < ws.sh_cap) sh_cap = ws.sh_cap;
+    cap = (cap + 63) & ~63LL;           // vectors are stored in tiles of 64 slots (load_soa / store_soa)
+    sh_cap = (sh_cap + 63) & ~63LL;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_workspace(ctx);
     const int n = ctx->dims;
@@ -1307,17 +1309,17 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     if (rc) return rc;
     Workspace ws = ctx->ws;
     hipStream_t s = ctx->stream;
-    // ray-major host arrays -> component-major device batch
-    std::vector<double> so((size_t)n * cnt), sv((size_t)n * cnt);
+    // ray-major host arrays -> the pool's tiles of 64 slots (component-major inside a tile)
+    const long long padded = (cnt + 63) & ~63LL;
+    std::vector<double> so((size_t)n * padded, 0.0), sv((size_t)n * padded, 0.0);
+    auto tile_at = [n](long long r, int c) { return (size_t)((r >> 6) * (long long)(n * 64) + c * 64 + (r & 63)); };
     for (long long r = 0; r < cnt; ++r)
         for (int c = 0; c < n; ++c) {
-            so[(size_t)c * cnt + r] = o[r * n + c];
-            sv[(size_t)c * cnt + r] = v[r * n + c];
+            so[tile_at(r, c)] = o[r * n + c];
+            sv[tile_at(r, c)] = v[r * n + c];
         }
-    for (int c = 0; c < n; ++c) {
-        HIP_TRY(hipMemcpyAsync(ws.ray_o + (size_t)c * ws.cap, so.data() + (size_t)c * cnt, cnt * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ws.ray_v + (size_t)c * ws.cap, sv.data() + (size_t)c * cnt, cnt * sizeof(double), hipMemcpyHostToDevice, s));
-    }
+    HIP_TRY(hipMemcpyAsync(ws.ray_o, so.data(), so.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ws.ray_v, sv.data(), sv.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ws.frac, dist_limit, cnt * sizeof(double), hipMemcpyHostToDevice, s));
     TraceJob tj{};
     tj.n_seg = 0;
@@ -1329,15 +1331,13 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(obj, ws.hit_obj, cnt * sizeof(int), hipMemcpyDeviceToHost, s));
-    for (int c = 0; c < n; ++c) {
-        HIP_TRY(hipMemcpyAsync(so.data() + (size_t)c * cnt, ws.hit_p + (size_t)c * ws.cap, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(sv.data() + (size_t)c * cnt, ws.hit_n + (size_t)c * ws.cap, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
+    HIP_TRY(hipMemcpyAsync(so.data(), ws.hit_p, so.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(sv.data(), ws.hit_n, sv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (long long r = 0; r < cnt; ++r)
         for (int c = 0; c < n; ++c) {
-            hit[r * n + c] = so[(size_t)c * cnt + r];
-            normal[r * n + c] = sv[(size_t)c * cnt + r];
+            hit[r * n + c] = so[tile_at(r, c)];
+            normal[r * n + c] = sv[tile_at(r, c)];
         }
     return NDT_OK;
 }

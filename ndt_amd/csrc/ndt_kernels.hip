@@ -49,15 +49,23 @@ NDT_DEV int wave_reserve(int *counter, int total)
     return __shfl(base, 0, 64);
 }
 
+// K-vectors of the node pool / shadow queue live in tiles of 64 slots, component-major inside the
+// tile: x[(g/64)*K*64 + c*64 + g%64].  A wavefront still reads component c of 64 consecutive slots
+// as one 512-byte request, but the K requests of a batch now fall into one K*512-byte block
+// instead of K regions `cap` doubles apart (one TLB entry / DRAM page per batch instead of K).
+// (`stride`, the pool capacity, is kept in the signature for the callers' sake; capacities are
+// multiples of 64.)
 template <int K> NDT_DEV void load_soa(const double *base, long long stride, long long g, double (&r)[K])
 {
+    const double *t = base + (g >> 6) * (long long)(K * 64) + (g & 63);
 #pragma unroll
-    for (int c = 0; c < K; ++c) r[c] = base[(long long)c * stride + g];
+    for (int c = 0; c < K; ++c) r[c] = t[c * 64];
 }
 template <int K> NDT_DEV void store_soa(double *base, long long stride, long long g, const double (&r)[K])
 {
+    double *t = base + (g >> 6) * (long long)(K * 64) + (g & 63);
 #pragma unroll
-    for (int c = 0; c < K; ++c) base[(long long)c * stride + g] = r[c];
+    for (int c = 0; c < K; ++c) t[c * 64] = r[c];
 }
 
 // ------------------------------------------------------------------ primary rays
@@ -162,60 +170,74 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         dense_count = live < 0 ? 0 : (live < dense_count ? live : dense_count);
         if (job.tail_ptr[2] != 0) dense_count = 0;      // pool overflow: the host retries with a larger pool
     }
-    const long long n_batches = seg_batches + ((dense_count + bs - 1) >> sh);
-    // The batches are split into NDT_QUEUE_SHARDS contiguous shards, each with its own head on
-    // its own cache line: a single head word saturates near 90 pops/us on MI355X, which a
-    // 32k-batch launch would feel.  A wavefront drains its home shard (workgroup id mod shards,
-    // i.e. the workgroups that share an XCD) and then steals from the others; it exits when
-    // every shard is empty.
-    const long long per_shard = (n_batches + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+    const long long dense_batches = (dense_count + bs - 1) >> sh;
+    const long long n_batches = dense_batches + seg_batches;
+    // Logical batch order: the dense part (closest-hit rays, the expensive ones) first, the
+    // shadow segments after it.  Logical batch L belongs to queue shard L % SHARDS, so every
+    // shard starts with expensive batches and ends with cheap ones: what is still running when
+    // the queue drains -- the tail every launch pays for -- is a cheap batch.
+    // Each shard has its own head on its own cache line (a single head word saturates near
+    // 90 pops/us on MI355X).  A wavefront drains its home shard (workgroup id mod shards, i.e. the
+    // workgroups that share an XCD) and then steals from the others; it exits when every shard
+    // is empty.  (Handing out several batches per pop was measured: the heads get cheaper, the
+    // tail gets longer, and the launch slower.)
     int shard_try = 0;
     const int home = blockIdx.x % NDT_QUEUE_SHARDS;
     while (true) {
-        long long b = -1;
+        long long b = -1;           // logical batch
         while (shard_try < NDT_QUEUE_SHARDS) {
             const int sh_i = (home + shard_try) % NDT_QUEUE_SHARDS;
-            const long long lo = sh_i * per_shard;
-            long long n_here = n_batches - lo;
-            if (n_here > per_shard) n_here = per_shard;
+            const long long n_here = (n_batches - sh_i + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
             int k = 0;
             if (n_here > 0) {
                 if (lane == 0) k = atomicAdd(job.queue + sh_i * NDT_QUEUE_STRIDE, 1);
                 k = __shfl(k, 0, 64);
             }
             if (n_here > 0 && k < n_here) {
-                b = lo + k;
+                b = (long long)k * NDT_QUEUE_SHARDS + sh_i;
                 break;
             }
             ++shard_try;       // this shard is drained for good
         }
         if (b < 0) break;
         long long g;
-        const bool in_seg = b < seg_batches;            // wave-uniform
+        const bool in_seg = b >= dense_batches;         // wave-uniform
         if (in_seg) {
-            // segment of batch b = number of segments whose inclusive prefix is <= b
-            const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= (int)b));
+            // segment of shadow batch sb = number of segments whose inclusive prefix is <= sb
+            const int sb = (int)(b - dense_batches);
+            const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= sb));
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
             const int cnt = __shfl(seg_cnt, s, 64);
-            const int idx = ((int)b - first) * bs + lane;
+            const int idx = (sb - first) * bs + lane;
             if (lane >= bs || idx >= cnt) continue;
             g = (long long)s * job.seg_stride + idx;
         } else {
-            const long long r = (b - seg_batches) * bs + lane;
+            const long long r = b * bs + lane;
             if (lane >= bs || r >= dense_count) continue;
             g = job.begin + r;
             if (job.dense.valid && job.dense.valid[g] <= 0) continue;
         }
         const TracePart &part = in_seg ? job.seg : job.dense;
         double o[N], v[N];
+#ifdef NDT_TRACE_SKIP_KNOB
+        if (job.skip_trace == 3) {
+            for (int c = 0; c < N; ++c) { o[c] = (double)g; v[c] = 1.0; }
+        } else
+#endif
+        {
         load_soa<N>(part.o, part.stride, g, o);
         load_soa<N>(part.v, part.stride, g, v);
+        }
         const double lim = part.lim ? part.lim[g] : -1.0;
         int obj, prim;
 #ifdef NDT_PHASE_TIMING
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         unsigned int occ[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         ph[6] += __builtin_readcyclecounter() - out_last;
+        if (job.skip_trace) {
+            obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;     // keeps the loads alive
+            prim = -1;
+        } else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ);
         out_last = __builtin_readcyclecounter();
         {
@@ -227,7 +249,16 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             acc[6] += 1ull;
         }
 #else
+#ifdef NDT_TRACE_SKIP_KNOB
+        if (job.skip_trace) {       // diagnostic build: what a launch costs without the traversal
+            obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;
+            prim = -1;
+        } else
+#endif
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
+#endif
+#ifdef NDT_TRACE_SKIP_KNOB
+        if (job.skip_trace == 2 && obj == -1) continue;
 #endif
         part.out_obj[g] = obj;
         part.out_prim[g] = prim;
@@ -275,6 +306,7 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
     static const int block = env_int("NDT_TRACE_BLOCK", NDT_TRACE_BLOCK);
     static const int force_batch = env_int("NDT_TRACE_BATCH", 0);
     job.batch = 64;
+    job.skip_trace = env_int("NDT_TRACE_SKIP", 0);
     if (force_batch == 64 || force_batch == 32 || force_batch == 16 || force_batch == 8) job.batch = force_batch;
     const long long upper = job.count + (job.n_seg > 0 ? job.seg_stride * job.n_seg : 0);      // sizes the grid only
     long long blocks = (upper + job.batch * (block / 64) - 1) / (job.batch * (block / 64));

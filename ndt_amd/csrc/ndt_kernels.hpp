@@ -71,6 +71,7 @@ struct TraceJob {
     const int *tail_ptr;        // device word holding the end of the dense range (node pool tail), or nullptr
     int *queue;                 // device-side work-queue heads for this launch (zeroed by the host)
     int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
+    int skip_trace;             // diagnostic build only: pop, load and store but do not traverse
 };
 
 struct LevelRange {
