@@ -1189,11 +1189,15 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             if (hc[2] != 0) { overflow = hc[2]; break; }
             for (int k = 0; k < n_seg; ++k) shadow_total += hc[16 + k];
             if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
-                unsigned long long d[32];
+                unsigned long long d[56];
                 if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
+                    fprintf(stderr, "ndt_hip: batch time inside trace_kd so far (100 MHz wall clock): closest max %.1f us mean %.1f us, shadow max %.1f us mean %.1f us\n",
+                            d[40] / 100.0, d[44] ? d[42] / 100.0 / d[44] : 0.0, d[41] / 100.0, d[45] ? d[43] / 100.0 / d[45] : 0.0);
                     fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
                     fprintf(stderr, "ndt_hip: cumulative per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
                             d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
+                    fprintf(stderr, "ndt_hip: per-ray maxima so far: %llu node visits, %llu gates, %llu intersections; per-batch maxima: %llu T, %llu G, %llu I iterations\n",
+                            d[46], d[47], d[48], d[49], d[50], d[51]);
                     for (int kind = 0; kind < 2; ++kind) {
                         const unsigned long long *q = d + 16 + 8 * kind;
                         fprintf(stderr, "ndt_hip: cumulative loop occupancy (%s rays): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     unsigned long long acc[24];                                  // [0..6] per-ray counts + rays, [8..13] / [16..21] loop occupancy
     for (int i = 0; i < 24; ++i) acc[i] = 0ull;
     unsigned long long out_last = __builtin_readcyclecounter();
+    unsigned long long batch_mark = 0;
 #endif
     // batches of `bs` rays (64, or fewer when the launch has too few rays to fill the chip: a
     // wavefront's time is set by its slowest lane, so half-empty wavefronts finish sooner and
@@ -234,12 +235,20 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         unsigned int occ[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         ph[6] += __builtin_readcyclecounter() - out_last;
+        batch_mark = wall_clock64();
         if (job.skip_trace) {
             obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;     // keeps the loads alive
             prim = -1;
         } else
         trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ);
         out_last = __builtin_readcyclecounter();
+        if (ws.dbg && lane == __ffsll((long long)__ballot(1)) - 1) {
+            // duration of this batch inside trace_kd: slowest batch of the launch (dbg[40 + is_shadow])
+            const unsigned long long now = wall_clock64();      // constant 100 MHz
+            atomicMax(&ws.dbg[40 + (int)in_seg], now - batch_mark);
+            atomicAdd(&ws.dbg[42 + (int)in_seg], now - batch_mark);
+            atomicAdd(&ws.dbg[44 + (int)in_seg], 1ull);
+        }
         {
             // every active lane holds the same per-wave occupancy numbers: the lowest active lane keeps them
             const unsigned long long act = __ballot(1);
@@ -247,6 +256,23 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
                 for (int i = 0; i < 6; ++i) acc[(in_seg ? 16 : 8) + i] += occ[i];
             for (int i = 0; i < 6; ++i) acc[i] += cnt[i];
             acc[6] += 1ull;
+            if (ws.dbg) {
+                // per-ray maxima: node visits, gates, intersections; and the same summed over the slowest lane's wave
+                unsigned int nv = cnt[0], ng = cnt[1] + cnt[3], ni = cnt[2] + cnt[4];
+                for (int d = 32; d > 0; d >>= 1) {
+                    nv = max(nv, (unsigned int)__shfl_xor((int)nv, d, 64));
+                    ng = max(ng, (unsigned int)__shfl_xor((int)ng, d, 64));
+                    ni = max(ni, (unsigned int)__shfl_xor((int)ni, d, 64));
+                }
+                if (lane == __ffsll((long long)__ballot(1)) - 1) {
+                    atomicMax(&ws.dbg[46], (unsigned long long)nv);
+                    atomicMax(&ws.dbg[47], (unsigned long long)ng);
+                    atomicMax(&ws.dbg[48], (unsigned long long)ni);
+                    atomicMax(&ws.dbg[49], (unsigned long long)occ[0]);     // T / G / I loop iterations of one batch
+                    atomicMax(&ws.dbg[50], (unsigned long long)occ[2]);
+                    atomicMax(&ws.dbg[51], (unsigned long long)occ[4]);
+                }
+            }
         }
 #else
 #ifdef NDT_TRACE_SKIP_KNOB
