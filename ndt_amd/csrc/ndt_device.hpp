@@ -975,6 +975,20 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             } else {
                 // ---- phase I: intersect
                 NDT_OCC(2);
+#ifdef NDT_PHASE_TIMING
+                {
+                    // how many different primitive types this I iteration executes, and how many lanes the commonest has
+                    const int ty = blob_int(blob, sd.off_hdr + 2 * prim, 0) & NDT_F_TYPE_MASK;
+                    int kinds = 0, top = 0;
+                    for (int t = 0; t < 9; ++t) {
+                        const int c = __popcll(__ballot(ty == t));
+                        kinds += c > 0;
+                        top = c > top ? c : top;
+                    }
+                    occ[6] += kinds;
+                    occ[7] += top;
+                }
+#endif
                 double res[N], nrm[N];
                 const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
                 if (ok) {

@@ -88,6 +88,7 @@ struct ndt_hip_ctx {
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
     int *h_counters = nullptr;      // pinned
+    LevelRange *h_levels = nullptr; // pinned, NDT_MAX_LEVELS + 1
     unsigned long long *h_ref = nullptr;   // pinned, 64 x 8
     std::vector<hipEvent_t> ev_pool;
 };
@@ -128,6 +129,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
         return fail(NDT_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     e = hipHostMalloc((void **)&ctx->h_counters, 128 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_levels, (NDT_MAX_LEVELS + 1) * sizeof(LevelRange), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -163,6 +165,7 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_levels) (void)hipHostFree(ctx->h_levels);
     if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
@@ -904,6 +907,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
     if ((rc = ws_alloc(ctx, &ws.dbg, 64))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
         if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return rc;
@@ -916,14 +920,40 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
 
 // ------------------------------------------------------------------ dimension-independent kernels
 
+// After shade_emit(level) has spawned the next bounce: publish its range, note the shadow rays
+// this bounce emitted, and clear the other parity's segment counters for the next shade_emit.
+// One wavefront.
+__global__ void k_level_step(Workspace ws, int level, int n_seg)
+{
+    const int lane = threadIdx.x;
+    int *seg = NDT_SEG_COUNTERS(ws, level);
+    long long mine = (lane < n_seg) ? seg[lane] : 0;
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    NDT_SEG_COUNTERS(ws, level + 1)[lane] = 0;
+    if (lane != 0) return;
+    const LevelRange cur = ws.levels[level];
+    ws.levels[level].n_shadow = mine;
+    LevelRange next;
+    next.begin = cur.begin + cur.count;
+    next.count = (long long)ws.counters[0] - next.begin;
+    next.n_shadow = 0;
+    if (next.count < 0 || ws.counters[2] != 0) next.count = 0;         // node pool overflow: the host retries
+    next.seg_stride = (next.count + 63) & ~63LL;
+    if ((long long)n_seg * next.seg_stride > ws.sh_cap) {
+        // the shadow queue cannot hold this bounce: flag it, tell the host how much it needs, stop here
+        atomicOr(&ws.counters[2], 2);
+        const long long need = (long long)n_seg * next.seg_stride;
+        ws.counters[3] = need > 0x7fffffffLL ? 0x7fffffff : (int)need;
+        next.count = 0;
+        next.seg_stride = 0;
+    }
+    ws.levels[level + 1] = next;
+}
+
 // Bottom-up combine of one bounce: get_ray_color's blend of its own colour with the colours
 // its reflection / refraction children returned (ndt.c:402-429), in the reference's order.
-__global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc sd, Workspace ws, int specular, long long begin,
-                                                 long long count)
+__device__ __forceinline__ void resolve_node(const double *blob, const SceneDesc &sd, const Workspace &ws, int specular, long long g)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= count) return;
-    const long long g = begin + r;
     if (ws.depth_left[g] <= 0) return;
     const int obj = ws.hit_obj[g];
     if (obj < 0) return;                        // background node: colour and count already final
@@ -956,6 +986,13 @@ __global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc s
     ws.clr[1 * ws.cap + g] = c[1];
     ws.clr[2 * ws.cap + g] = c[2];
     ws.count[g] = cnt;
+}
+
+__global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc sd, Workspace ws, int specular, int level)
+{
+    const LevelRange lr = ws.levels[level];
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < lr.count; r += (long long)gridDim.x * blockDim.x)
+        resolve_node(blob, sd, ws, specular, lr.begin + r);
 }
 
 // get_pixel_color's adaptive loop (ndt.c:488-568) replayed on the one deterministic sample:
@@ -1110,22 +1147,27 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 64 * 8 * sizeof(unsigned long long), s));
         HIP_TRY(hipMemsetAsync(ws.dbg, 0, 64 * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)NDT_QUEUE_SLOTS * NDT_QUEUE_INTS * sizeof(int), s));
+        // work-queue heads of every launch of the frame + both parities of the shadow-segment counters
+        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)(NDT_CNT_TOTAL - NDT_CNT_QUEUE) * sizeof(int), s));
+        // The whole frame is enqueued without reading anything back: the range of every bounce
+        // is published on the device (k_level_step) and read there.  Bounce 0 = the primaries.
+        const int n_seg = ctx->n_shadow_lights;
+        const int n_levels = rg.max_depth > 1 ? rg.max_depth : 1;      // a node spawns children only while depth_left > 1
+        int n_run = n_levels;                                           // bounces actually enqueued
+        LevelRange *hl = ctx->h_levels;
+        hl[0].begin = 0;
+        hl[0].count = rg.n_primary;
+        hl[0].seg_stride = (rg.n_primary + 63) & ~63LL;
+        hl[0].n_shadow = 0;
+        if ((long long)n_seg * hl[0].seg_stride > ws.sh_cap) {
+            sh_cap = (long long)n_seg * hl[0].seg_stride;
+            continue;
+        }
+        HIP_TRY(hipMemcpyAsync(ws.levels, hl, sizeof(LevelRange), hipMemcpyHostToDevice, s));
         int queue_slot = 0;
-        kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
-
-        std::vector<LevelRange> levels;
-        LevelRange lr{ 0, rg.n_primary, 0 };
-        long long shadow_total = 0;
-        int overflow = 0;
         int launches = 0;
-        // closest-hit queries of the primaries: the only launch that is not shared
-        {
-            TraceJob tj{};
-            tj.n_seg = 0;
-            tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
-            tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
-            tj.begin = 0; tj.count = rg.n_primary; tj.tail_ptr = nullptr;
+        kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+        auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
@@ -1133,109 +1175,104 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
                 HIP_TRY(hipEventRecord(b2, s));
                 trace_ev.push_back({ a, b2 });
-                trace_dbg.push_back("closest 0: " + std::to_string(rg.n_primary) + " rays");
+                trace_dbg.push_back(what);
             } else {
                 kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
             }
             ++launches;
+            return NDT_OK;
+        };
+        // closest-hit queries of the primaries: the only launch that is not shared
+        {
+            TraceJob tj{};
+            tj.n_seg = 0;
+            tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
+            tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
+            tj.begin = 0; tj.count = rg.n_primary; tj.levels = nullptr;
+            if ((rc = traced(tj, "closest 0"))) return rc;
         }
-        while (lr.count > 0) {
-            levels.push_back(lr);
-            if (queue_slot + 1 > NDT_QUEUE_SLOTS) return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
-            // shadow queue: one segment per non-ambient light, each able to hold the whole bounce
-            const int n_seg = ctx->n_shadow_lights;
-            lr.seg_stride = (lr.count + 63) & ~63LL;
-            if ((long long)n_seg * lr.seg_stride > ws.sh_cap) {
-                overflow = 2;
-                sh_cap = (long long)n_seg * lr.seg_stride;      // doubled below
-                break;
-            }
-            levels.back() = lr;
-            HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_SEG, 0, 64 * sizeof(int), s));
+        long long upper = rg.n_primary;         // bound on the node count of the bounce (each node spawns at most two)
+        for (int b = 0; b < n_levels; ++b) {
+            if (queue_slot + 1 > NDT_QUEUE_SLOTS || b + 1 > NDT_MAX_LEVELS)
+                return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
+            if (upper > ws.cap) upper = ws.cap;
             // hit points, shadow rays of this bounce, and the rays of the next bounce
-            kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, lr);
-            const long long next_begin = lr.begin + lr.count;
+            kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+            hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg);
+            long long next_upper = 2 * upper;
+            if (next_upper > ws.cap) next_upper = ws.cap;
             {
                 // ONE launch: shadow rays of bounce b + closest-hit rays of bounce b+1
                 TraceJob tj{};
                 tj.n_seg = n_seg;
                 tj.seg.o = ws.so; tj.seg.v = ws.sv; tj.seg.stride = ws.sh_cap; tj.seg.lim = ws.slim; tj.seg.valid = nullptr;
                 tj.seg.out_obj = ws.sobj; tj.seg.out_prim = ws.sprim;
-                tj.seg_count = ws.counters + NDT_CNT_SEG; tj.seg_stride = lr.seg_stride;
+                tj.seg_count = NDT_SEG_COUNTERS(ws, b);
+                tj.seg_stride = (upper + 63) & ~63LL;           // sizes the grid only
                 tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
                 tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
-                tj.begin = next_begin;
-                tj.count = 2 * lr.count;                        // at most two children per node
-                if (tj.count > ws.cap - next_begin) tj.count = ws.cap - next_begin;
-                tj.tail_ptr = ws.counters;                      // node pool tail, advanced by shade_emit
-                tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
-                if (prof) {
-                    hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
-                    HIP_TRY(hipEventRecord(a, s));
-                    kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
-                    HIP_TRY(hipEventRecord(b2, s));
-                    trace_ev.push_back({ a, b2 });
-                    trace_dbg.push_back("shadow " + std::to_string(levels.size() - 1) + " + closest " + std::to_string(levels.size()));
-                } else {
-                    kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
-                }
-                ++launches;
+                tj.begin = 0;
+                tj.count = next_upper;                          // sizes the grid only
+                tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = b + 1;
+                if ((rc = traced(tj, "shadow " + std::to_string(b) + " + closest " + std::to_string(b + 1)))) return rc;
             }
-            kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, lr);
-            HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(hc + 16, ws.counters + NDT_CNT_SEG, 64 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipGetLastError());
-            if (hc[2] != 0) { overflow = hc[2]; break; }
-            for (int k = 0; k < n_seg; ++k) shadow_total += hc[16 + k];
-            if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
-                unsigned long long d[56];
-                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
-                    fprintf(stderr, "ndt_hip: batch time inside trace_kd so far (100 MHz wall clock): closest max %.1f us mean %.1f us, shadow max %.1f us mean %.1f us\n",
-                            d[40] / 100.0, d[44] ? d[42] / 100.0 / d[44] : 0.0, d[41] / 100.0, d[45] ? d[43] / 100.0 / d[45] : 0.0);
-                    fprintf(stderr, "ndt_hip: cumulative wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
-                    fprintf(stderr, "ndt_hip: cumulative per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
-                            d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
-                    fprintf(stderr, "ndt_hip: per-ray maxima so far: %llu node visits, %llu gates, %llu intersections; per-batch maxima: %llu T, %llu G, %llu I iterations\n",
-                            d[46], d[47], d[48], d[49], d[50], d[51]);
-                    for (int kind = 0; kind < 2; ++kind) {
-                        const unsigned long long *q = d + 16 + 8 * kind;
-                        fprintf(stderr, "ndt_hip: cumulative loop occupancy (%s rays): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
-                                kind ? "shadow" : "closest", q[0] ? 100.0 * q[1] / (64.0 * q[0]) : 0.0, q[0],
-                                q[2] ? 100.0 * q[3] / (64.0 * q[2]) : 0.0, q[2], q[4] ? 100.0 * q[5] / (64.0 * q[4]) : 0.0, q[4]);
-                    }
+            kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+            upper = next_upper;
+            // deep recursion limits (-l 50): look every 8 bounces whether the tree has died out
+            if ((b & 7) == 7 && b + 1 < n_levels) {
+                HIP_TRY(hipMemcpyAsync(hl + b + 1, ws.levels + b + 1, sizeof(LevelRange), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (hl[b + 1].count <= 0) {
+                    n_run = b + 1;
+                    break;
                 }
-                long long sh = 0;
-                for (int k = 0; k < n_seg; ++k) sh += hc[16 + k];
-                fprintf(stderr, "ndt_hip: bounce %zu: %lld nodes, %lld shadow rays\n", levels.size() - 1, lr.count, sh);
             }
-            lr.begin = next_begin;
-            lr.count = (long long)hc[0] - next_begin;
-        }
-        if (overflow) {
-            if (overflow & 1) cap *= 2;
-            if (overflow & 2) sh_cap *= 2;
-            continue;
         }
         // bottom-up colour resolve, deepest bounce first (the primaries last)
-        for (size_t li = levels.size(); li-- > 0;) {
-            const LevelRange &L = levels[li];
-            hipLaunchKernelGGL(k_resolve, dim3((unsigned)((L.count + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
-                               rg.specular, L.begin, L.count);
+        {
+            std::vector<long long> ub((size_t)n_run);
+            long long u = rg.n_primary;
+            for (int b = 0; b < n_run; ++b) {
+                ub[b] = u > ws.cap ? ws.cap : u;
+                u = 2 * ub[b];
+            }
+            for (int b = n_run; b-- > 0;) {
+                long long blocks = (ub[b] + 255) / 256;
+                if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
+                hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws, rg.specular, b);
+            }
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
                            rg, ctx->dims, (double *)d_rgba);
+        HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
         unsigned long long ref_rays = 0;
         HIP_TRY(hipMemcpyAsync(ctx->h_ref, ws.ref_rays, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if (prof) HIP_TRY(hipEventRecord(ev_end, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
+        if (hc[2] != 0) {
+            // a pool overflowed somewhere in the frame: grow it and render again
+            if (hc[2] & 1) cap *= 2;
+            if (hc[2] & 2) {
+                sh_cap *= 2;
+                if (sh_cap < hc[3]) sh_cap = hc[3];
+            }
+            continue;
+        }
         for (int k = 0; k < 64; ++k) ref_rays += ctx->h_ref[8 * k];
+        long long shadow_total = 0;
+        int levels_used = 0;
+        for (int b = 0; b < n_run; ++b) {
+            if (hl[b].count <= 0) break;
+            shadow_total += hl[b].n_shadow;
+            ++levels_used;
+        }
         st.rays_primary = n_pixels;
         st.rays_secondary = (long long)hc[0] - rg.n_primary;
         st.rays_shadow = shadow_total;
         st.rays_ref_equiv = (long long)ref_rays;
-        st.levels = (int)levels.size();
+        st.levels = levels_used;
         st.trace_launches = launches;
         st.node_capacity = ws.cap;
         if (prof) {
@@ -1247,6 +1284,31 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
             }
             st.trace_ms = ms;
             if (getenv("NDT_HIP_DEBUG_LEVELS")) {
+                for (int b = 0; b < levels_used; ++b)
+                    fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
+                unsigned long long d[64];
+                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
+                    // NDT_PHASE_TIMING builds only (make -C ndt_amd/csrc timing)
+                    fprintf(stderr, "ndt_hip: wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
+                    fprintf(stderr, "ndt_hip: per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
+                            d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
+                    fprintf(stderr, "ndt_hip: batch time inside trace_kd (100 MHz wall clock): closest max %.1f us mean %.1f us, shadow max %.1f us mean %.1f us\n",
+                            d[40] / 100.0, d[44] ? d[42] / 100.0 / d[44] : 0.0, d[41] / 100.0, d[45] ? d[43] / 100.0 / d[45] : 0.0);
+                    fprintf(stderr, "ndt_hip: per-ray maxima: %llu node visits, %llu gates, %llu intersections; per-batch maxima: %llu T, %llu G, %llu I iterations\n",
+                            d[46], d[47], d[48], d[49], d[50], d[51]);
+                    if (d[58])
+                        fprintf(stderr, "ndt_hip: shade_emit per wavefront (wall-clock ticks, mean over %llu): load+isect %.0f, light tests %.0f, segment reserve %.0f, shadow stores %.0f, spawn %.0f; slowest wavefront %llu\n",
+                                d[58], (double)d[52] / d[58], (double)d[53] / d[58], (double)d[54] / d[58], (double)d[55] / d[58], (double)d[56] / d[58], d[59]);
+                    for (int kind = 0; kind < 2; ++kind) {
+                        const unsigned long long *q = d + 16 + 8 * kind;
+                        fprintf(stderr, "ndt_hip: loop occupancy (%s rays): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
+                                kind ? "shadow" : "closest", q[0] ? 100.0 * q[1] / (64.0 * q[0]) : 0.0, q[0],
+                                q[2] ? 100.0 * q[3] / (64.0 * q[2]) : 0.0, q[2], q[4] ? 100.0 * q[5] / (64.0 * q[4]) : 0.0, q[4]);
+                        if (q[4])
+                            fprintf(stderr, "ndt_hip:    I iterations execute %.2f primitive types on average; the commonest type holds %.1f of %.1f active lanes\n",
+                                    (double)q[6] / q[4], (double)q[7] / q[4], (double)q[5] / q[4]);
+                    }
+                }
                 for (size_t i = 0; i < trace_ev.size(); ++i) {
                     float m = 0;
                     (void)hipEventElapsedTime(&m, trace_ev[i].first, trace_ev[i].second);
@@ -1328,7 +1390,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     TraceJob tj{};
     tj.n_seg = 0;
     tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = ws.frac; tj.dense.valid = nullptr;
-    tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.tail_ptr = nullptr;
+    tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.levels = nullptr;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);

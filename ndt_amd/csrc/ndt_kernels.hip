@@ -165,11 +165,12 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         const int excl = wave_excl_scan((seg_cnt + bs - 1) >> sh, seg_batches);
         seg_batches_incl = excl + ((seg_cnt + bs - 1) >> sh);
     }
-    long long dense_count = job.count;
-    if (job.tail_ptr) {
-        const long long live = (long long)*job.tail_ptr - job.begin;    // produced earlier on this stream
-        dense_count = live < 0 ? 0 : (live < dense_count ? live : dense_count);
-        if (job.tail_ptr[2] != 0) dense_count = 0;      // pool overflow: the host retries with a larger pool
+    long long dense_count = job.count, dense_begin = job.begin, seg_stride = job.seg_stride;
+    if (job.levels) {
+        // ranges produced earlier on this stream (k_level_step)
+        dense_begin = job.levels[job.dense_level].begin;
+        dense_count = job.levels[job.dense_level].count;
+        seg_stride = job.levels[job.seg_level].seg_stride;
     }
     const long long dense_batches = (dense_count + bs - 1) >> sh;
     const long long n_batches = dense_batches + seg_batches;
@@ -211,11 +212,11 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             const int cnt = __shfl(seg_cnt, s, 64);
             const int idx = (sb - first) * bs + lane;
             if (lane >= bs || idx >= cnt) continue;
-            g = (long long)s * job.seg_stride + idx;
+            g = (long long)s * seg_stride + idx;
         } else {
             const long long r = b * bs + lane;
             if (lane >= bs || r >= dense_count) continue;
-            g = job.begin + r;
+            g = dense_begin + r;
             if (job.dense.valid && job.dense.valid[g] <= 0) continue;
         }
         const TracePart &part = in_seg ? job.seg : job.dense;
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             // every active lane holds the same per-wave occupancy numbers: the lowest active lane keeps them
             const unsigned long long act = __ballot(1);
             if (lane == __ffsll((long long)act) - 1)
-                for (int i = 0; i < 6; ++i) acc[(in_seg ? 16 : 8) + i] += occ[i];
+                for (int i = 0; i < 8; ++i) acc[(in_seg ? 16 : 8) + i] += occ[i];
             for (int i = 0; i < 6; ++i) acc[i] += cnt[i];
             acc[6] += 1ull;
             if (ws.dbg) {
@@ -362,6 +363,18 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
 
 // ------------------------------------------------------------------ shading, first half
 
+#ifdef NDT_PHASE_TIMING
+// diagnostic build: wall-clock (100 MHz) stamps of lane 0 of every wavefront, summed per section
+#define NDT_SEC_BEGIN() unsigned long long sec_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long sec_last = wall_clock64(); const unsigned long long sec_first = sec_last
+#define NDT_SEC(k) do { const unsigned long long now_ = wall_clock64(); sec_t[k] += now_ - sec_last; sec_last = now_; } while (0)
+#define NDT_SEC_END(base) do { if (ws.dbg && __lane_id() == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&ws.dbg[(base) + i_], sec_t[i_]); \
+        atomicAdd(&ws.dbg[(base) + 6], 1ull); atomicMax(&ws.dbg[(base) + 7], wall_clock64() - sec_first); } } while (0)
+#else
+#define NDT_SEC_BEGIN() do { } while (0)
+#define NDT_SEC(k) do { } while (0)
+#define NDT_SEC_END(base) do { } while (0)
+#endif
+
 struct LightRec {
     int type;
     double red, green, blue, angle;
@@ -417,15 +430,15 @@ NDT_DEV bool light_setup(const double *blob, const SceneDesc &sd, int li, const 
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg,
-                                                    LevelRange lr)
+NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
+                             const LevelRange &lr, int level, long long r)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = r < lr.count;
     const long long g = lr.begin + (in_range ? r : 0);
     bool shaded = false;
     double src[N], look[N], hit[N], nrm[N];
     int obj = -1;
+    NDT_SEC_BEGIN();
     if (in_range && ws.depth_left[g] > 0) {
         obj = ws.hit_obj[g];
         if (obj >= 0) {
@@ -459,6 +472,7 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
     // waits for a single atomic round trip however many lights there are.
     const int lane = __lane_id();
     unsigned long long fire = 0ull;
+    NDT_SEC(0);
     if (shaded) {
         for (int li = 0; li < sd.n_lights; ++li) {
             int type;
@@ -467,6 +481,7 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
             if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss)) fire |= 1ull << li;
         }
     }
+    NDT_SEC(1);
     // lane s learns how many lanes fire segment s's light, and which light that is
     int my_total = 0, seg = 0;
     for (int li = 0; li < sd.n_lights; ++li) {
@@ -476,8 +491,12 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
         ++seg;
     }
     int my_base = 0;
-    if (my_total > 0) my_base = atomicAdd(&ws.counters[NDT_CNT_SEG + lane], my_total);
+    if (my_total > 0) my_base = atomicAdd(&NDT_SEG_COUNTERS(ws, level)[lane], my_total);
     if (shaded) ws.sh_mask[g] = fire;
+#ifdef NDT_PHASE_TIMING
+    seg = __shfl(my_base, 0, 64) & 0;      // forces the atomic's round trip into section 2
+#endif
+    NDT_SEC(2);
     seg = 0;
     for (int li = 0; li < sd.n_lights; ++li) {
         if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
@@ -504,6 +523,7 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
         ++seg;
     }
 
+    NDT_SEC(3);
     // get_ray_color, ndt.c:381-430: spawn reflection / refraction.  The children depend on the
     // hit only, not on the lighting, so they are created here -- before the shadow rays of this
     // bounce are traced -- and the host traces them in the SAME launch as those shadow rays.
@@ -578,14 +598,25 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
         ws.sh_mask[c] = 0ull;
         ws.child_refr[g] = (int)c;
     }
+    NDT_SEC(4);
+    NDT_SEC_END(52);
+}
+
+// The bounce's range comes from the device-side table; the grid is sized for the host's upper
+// bound, workgroups past the end leave at once.  (A grid-stride loop here cost 50 VGPRs and
+// half the occupancy.)
+__global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
+{
+    const LevelRange lr = ws.levels[level];
+    const long long base = (long long)blockIdx.x * blockDim.x;
+    if (base < lr.count) shade_emit_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
 }
 
 // ------------------------------------------------------------------ shading, second half
 
-__global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg,
-                                                      LevelRange lr)
+NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
+                               const LevelRange &lr, int level, long long r)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = r < lr.count;
     const long long g = lr.begin + (in_range ? r : 0);
     int obj = -1;
@@ -675,6 +706,13 @@ __global__ void __launch_bounds__(256) k_shade_finish(const double *blob, SceneD
     }
 }
 
+__global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
+{
+    const LevelRange lr = ws.levels[level];
+    const long long base = (long long)blockIdx.x * blockDim.x;
+    if (base < lr.count) shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+}
+
 // ------------------------------------------------------------------ hit points for the trace_kd batch API
 
 __global__ void __launch_bounds__(256) k_hitpoints(const double *blob, SceneDesc sd, const double *o, const double *v,
@@ -704,15 +742,16 @@ static void launch_primary(hipStream_t s, const double *blob, SceneDesc sd, Work
 {
     hipLaunchKernelGGL(k_primary, dim3(grid_for(rg.n_primary, 256)), dim3(256), 0, s, blob, sd, ws, rg);
 }
-static void launch_shade_emit(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, LevelRange lr)
+static unsigned shade_grid(long long upper) { return grid_for(upper, 256); }
+static void launch_shade_emit(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper)
 {
-    if (lr.count <= 0) return;
-    hipLaunchKernelGGL(k_shade_emit, dim3(grid_for(lr.count, 256)), dim3(256), 0, s, blob, sd, ws, rg, lr);
+    if (upper <= 0) return;
+    hipLaunchKernelGGL(k_shade_emit, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level);
 }
-static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, LevelRange lr)
+static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper)
 {
-    if (lr.count <= 0) return;
-    hipLaunchKernelGGL(k_shade_finish, dim3(grid_for(lr.count, 256)), dim3(256), 0, s, blob, sd, ws, rg, lr);
+    if (upper <= 0) return;
+    hipLaunchKernelGGL(k_shade_finish, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level);
 }
 static void launch_hitpoints(hipStream_t s, const double *blob, SceneDesc sd, const double *o, const double *v,
                              long long stride, const int *prim, double *hit, double *nrm, long long count)

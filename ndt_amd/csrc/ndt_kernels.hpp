@@ -5,6 +5,17 @@
 #include <stdint.h>
 #include "ndt_device.hpp"
 
+// One bounce of the ray tree.  The table lives in device memory (Workspace::levels): bounce b+1
+// is written by k_level_step after shade_emit(b) has spawned its nodes, and every kernel of a
+// bounce reads its range from there, so the host enqueues a whole frame without reading anything
+// back in between.
+struct LevelRange {
+    long long begin, count;     // nodes of the bounce
+    long long seg_stride;       // capacity of one light's shadow segment for this bounce (>= count, multiple of 64)
+    long long n_shadow;         // shadow rays the bounce emitted (statistics)
+};
+#define NDT_MAX_LEVELS 1024
+
 // Device workspace of one render call.  Ray-tree nodes of all bounces live in one pool
 // (structure of arrays, component-major: x[c*cap + g]) so that lane g and lane g+1 touch
 // adjacent doubles -- one coalesced 512-byte request per component per wavefront.
@@ -33,6 +44,7 @@ struct Workspace {
     unsigned long long *mask_slab;  // visit masks for scenes too big for registers
     long long mask_slab_lanes;
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
+    LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
 };
 
 struct RenderGeom {
@@ -64,20 +76,17 @@ struct TracePart {
 struct TraceJob {
     TracePart seg;
     const int *seg_count;
-    long long seg_stride;
+    long long seg_stride;       // (taken from levels[seg_level] when `levels` is set)
     int n_seg;                  // 0 => no segmented part
     TracePart dense;
-    long long begin, count;     // dense range; count is an upper bound when tail_ptr is set
-    const int *tail_ptr;        // device word holding the end of the dense range (node pool tail), or nullptr
+    long long begin, count;     // dense range (taken from levels[dense_level] when `levels` is set; count then only sizes the grid)
+    const LevelRange *levels;   // device-side bounce table, or nullptr
+    int seg_level, dense_level;
     int *queue;                 // device-side work-queue heads for this launch (zeroed by the host)
     int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
     int skip_trace;             // diagnostic build only: pop, load and store but do not traverse
 };
 
-struct LevelRange {
-    long long begin, count;     // nodes of the bounce being processed
-    long long seg_stride;       // capacity of one light's shadow segment for this bounce (>= count)
-};
 
 // One table per compiled dimension.
 struct NdtKernelTable {
@@ -85,8 +94,9 @@ struct NdtKernelTable {
     void (*primary)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom);
     // tier: 0 = scene staged in LDS, visit mask in registers; 1 = scene in global memory, mask in the slab
     void (*trace)(hipStream_t, const double *blob, SceneDesc, Workspace, TraceJob, int tier, int mask_words);
-    void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, LevelRange);
-    void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, LevelRange);
+    // `upper` bounds the bounce's node count (sizes the grid); the range itself is ws.levels[level]
+    void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
+    void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
     void (*hitpoints)(hipStream_t, const double *blob, SceneDesc, const double *o, const double *v, long long stride,
                       const int *prim, double *hit, double *nrm, long long count);
 };
@@ -106,6 +116,8 @@ extern "C" const NdtKernelTable *ndt_kernel_table_8();
 #define NDT_QUEUE_INTS (NDT_QUEUE_SHARDS * NDT_QUEUE_STRIDE)
 #define NDT_CNT_QUEUE 16
 #define NDT_CNT_SEG (NDT_CNT_QUEUE + NDT_QUEUE_SLOTS * NDT_QUEUE_INTS)
-#define NDT_CNT_TOTAL (NDT_CNT_SEG + 64)
+#define NDT_CNT_TOTAL (NDT_CNT_SEG + 128)         /* shadow-segment counters, double-buffered by bounce parity */
+#define NDT_SEG_COUNTERS(ws, level) ((ws).counters + NDT_CNT_SEG + 64 * ((level) & 1))
+#define NDT_SHADE_MAX_BLOCKS 8192            /* shade kernels walk longer bounces with a grid-stride loop */
 #define NDT_TRACE_LDS_LIMIT (64 * 1024)     /* bytes of scene staged per workgroup: two workgroups per CU */
 #define NDT_MASK_REG_WORDS 4                /* 64-bit words of visit mask kept in registers (256 items) */
