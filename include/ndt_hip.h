@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NDT_HIP_ABI_VERSION 1
+#define NDT_HIP_ABI_VERSION 2
 
 /* Dimensions the gfx950 kernels are instantiated for.  The reference accepts any N >= 3
  * (ndt.c:1450 `-d`); BASELINE.json's configs span 3..8. */
@@ -141,6 +141,16 @@ typedef struct ndt_flat_scene {
     const int32_t         *leaf_refs; int32_t n_leaf_refs;   /* object indices (< n_items) */
     const int32_t         *inf_refs;  int32_t n_inf;         /* infinite objects, kd-tree.c:459 */
     int32_t bb_lower_off, bb_upper_off;                      /* root AABB, into vecs */
+
+    /* ABI 2 -- the rest of the camera (camera.h:34-76), used by recursive anti-aliasing, stereo
+     * modes and the VR / panorama cameras; offsets into vecs, -1 when the producer has none.
+     * cam_aperture_radius != 0 makes recursive AA and samples>1 draw from the reference's global
+     * drand48 stream (ndt.c:528-542): such frames are rejected, parity would only be statistical. */
+    double  cam_aperture_radius;
+    double  cam_h_fov, cam_v_fov;                            /* camera.h:52-53 */
+    int32_t cam_left_eye_off, cam_right_eye_off;             /* camera.h:60-61 */
+    int32_t cam_local_x_off, cam_local_y_off, cam_local_z_off;   /* camera.h:69-71 */
+    int32_t _pad2;
 } ndt_flat_scene;
 
 /* Arguments of one render_image call (ndt.c:900).  Rows are dealt cyclically exactly like the
@@ -154,6 +164,16 @@ typedef struct ndt_render_params {
     int32_t row_begin, row_step;
     int32_t specular;           /* 1 = specular_enabled (ndt.c:41) */
     int32_t profile;            /* 1 = bracket trace kernels with hipEvents (fills *_ms below) */
+    /* ABI 2.  Whitted's recursive anti-aliasing (`-a diff,depth`; ndt.c:655-733, 1039-1087): the
+     * first pass renders (width+1) x (height+1) corner samples, every output pixel is the average
+     * of its four corners and is subdivided (5 new samples per level, up to aa_depth+1 levels)
+     * while the corners differ by more than aa_diff/255.  The output is the resampled image
+     * (width x height doubles; the reference quantises it to 8 bits when it stores it). */
+    int32_t recursive_aa;       /* 0 = off */
+    int32_t aa_diff;            /* reference default 20 (ndt.c:1412) */
+    int32_t aa_depth;           /* reference default 4 (ndt.c:1411) */
+    int32_t stereo;             /* ndt_stereo_mode; only NDT_STEREO_MONO so far */
+    int32_t reserved[4];        /* must be 0 */
 } ndt_render_params;
 
 typedef struct ndt_render_stats {
@@ -167,6 +187,9 @@ typedef struct ndt_render_stats {
     double  trace_ms;           /* summed device time of those launches (profile=1) */
     double  frame_ms;           /* device time of the whole call (profile=1) */
     int64_t node_capacity;      /* ray-tree nodes the workspace holds */
+    /* ABI 2 */
+    int64_t pixels_resampled;   /* recursive AA: pixels that were subdivided (the reference's "pixels resampled") */
+    int64_t aa_samples;         /* recursive AA: extra get_pixel_color samples rendered by the second pass */
 } ndt_render_stats;
 
 typedef struct ndt_hip_ctx ndt_hip_ctx;

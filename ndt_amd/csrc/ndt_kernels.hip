@@ -77,28 +77,38 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= rg.n_primary) return;
-    const int tile = (int)(g >> 6), lane = (int)(g & 63);
-    const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
-    const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
     ws.child_refl[g] = -1;
     ws.child_refr[g] = -1;
     ws.count[g] = 0;
     ws.sh_mask[g] = 0ull;
-    if (px >= rg.width || py >= rg.rows) {
+    double ip, jp;              // image position in pixels (ndt.c:590-592)
+    bool live;
+    if (rg.samples) {
+        live = g < rg.n_samples;
+        ip = live ? rg.samples[2 * g] : 0.0;
+        jp = live ? rg.samples[2 * g + 1] : 0.0;
+    } else {
+        const int tile = (int)(g >> 6), lane = (int)(g & 63);
+        const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
+        const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
+        live = px < rg.width && py < rg.rows;
+        ip = px;
+        jp = rg.row_pair ? rg.row_begin + (py >> 1) * rg.row_step + (py & 1) : rg.row_begin + py * rg.row_step;
+    }
+    if (!live) {
         ws.depth_left[g] = 0;       // padding slot: never traced, never shaded
         ws.hit_obj[g] = -1;
         return;
     }
-    const int j = rg.row_begin + py * rg.row_step;
-    const double x = px / (double)rg.width - 0.5;               // ndt.c:632
-    const double y = -(j / (double)rg.height - 0.5);            // ndt.c:633
+    const double x = ip / (double)rg.img_w - 0.5;               // ndt.c:632
+    const double y = -(jp / (double)rg.img_h - 0.5);            // ndt.c:633
     double pos[N], orig[N], dx[N], dy[N], pixel[N], temp[N], look[N];
     blob_vec<N>(blob, sd.off_cam, pos);
     blob_vec<N>(blob, sd.off_cam + N, orig);
     blob_vec<N>(blob, sd.off_cam + 2 * N, dx);
     blob_vec<N>(blob, sd.off_cam + 3 * N, dy);
     const double focal = blob[sd.off_cam + 4 * N];
-    v_scale<N>(dx, rg.width / (double)rg.height, dx);           // ndt.c:926
+    v_scale<N>(dx, rg.aspect_w / (double)rg.aspect_h, dx);      // ndt.c:926
     v_copy<N>(pixel, orig);
     v_scale<N>(dx, x, temp);
     v_add<N>(pixel, temp, pixel);

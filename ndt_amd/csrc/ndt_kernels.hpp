@@ -47,14 +47,22 @@ struct Workspace {
     LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
 };
 
+// What the primary rays of one pass are.  Grid mode: the pixels of `rows` image rows of a
+// width-wide image, in 8x8 tiles (one wavefront = one tile); list mode (`samples` set): arbitrary
+// image positions, one per slot (the extra samples of the recursive anti-aliasing pass).
 struct RenderGeom {
-    int width, height;          // full image
-    int row_begin, row_step;    // shard
+    int width, height;          // grid: pixels per row / (unused); also the output row stride
+    int row_begin, row_step;    // shard: grid row r is image row row_begin + r*row_step ...
+    int row_pair;               // ... or, when set, row_begin + (r/2)*row_step + r%2 (corner rows of the AA pass)
     int rows;                   // rows of this shard
     int tiles_x, tiles_y;       // 8x8 tiles over (width, rows)
-    int n_primary;              // tiles_x*tiles_y*64 (padding slots included)
+    int n_primary;              // grid: tiles_x*tiles_y*64; list: n_samples rounded up to 64 (padding slots included)
     int max_depth;
     int specular;
+    int img_w, img_h;           // x = i/img_w - 0.5, y = -(j/img_h - 0.5)  (ndt.c:632-633)
+    int aspect_w, aspect_h;     // cam.dirX *= aspect_w/aspect_h            (ndt.c:926)
+    const double *samples;      // list mode: (i, j) per sample, in pixels of the img_w x img_h image
+    int n_samples;
 };
 
 // One k_trace launch = up to two parts, served from one work queue:

@@ -10,7 +10,7 @@ import ctypes as C
 import gzip
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MIN_DIMS, MAX_DIMS = 3, 8
 
 OBJ_TYPES = ["sphere", "hplane", "hdisk", "cylinder", "hcylinder", "orthotope", "hcube", "hfacet", "facet"]
@@ -60,19 +60,26 @@ class FlatSceneStruct(C.Structure):
                 ("kd_nodes", C.POINTER(FlatKdNode)), ("n_kd_nodes", C.c_int32),
                 ("leaf_refs", C.POINTER(C.c_int32)), ("n_leaf_refs", C.c_int32),
                 ("inf_refs", C.POINTER(C.c_int32)), ("n_inf", C.c_int32),
-                ("bb_lower_off", C.c_int32), ("bb_upper_off", C.c_int32)]
+                ("bb_lower_off", C.c_int32), ("bb_upper_off", C.c_int32),
+                ("cam_aperture_radius", C.c_double), ("cam_h_fov", C.c_double), ("cam_v_fov", C.c_double),
+                ("cam_left_eye_off", C.c_int32), ("cam_right_eye_off", C.c_int32),
+                ("cam_local_x_off", C.c_int32), ("cam_local_y_off", C.c_int32), ("cam_local_z_off", C.c_int32),
+                ("_pad2", C.c_int32)]
 
 
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_optic_depth", C.c_int32),
                 ("samples", C.c_int32), ("row_begin", C.c_int32), ("row_step", C.c_int32),
-                ("specular", C.c_int32), ("profile", C.c_int32)]
+                ("specular", C.c_int32), ("profile", C.c_int32),
+                ("recursive_aa", C.c_int32), ("aa_diff", C.c_int32), ("aa_depth", C.c_int32),
+                ("stereo", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class RenderStats(C.Structure):
     _fields_ = [("rays_primary", C.c_int64), ("rays_secondary", C.c_int64), ("rays_shadow", C.c_int64),
                 ("rays_ref_equiv", C.c_int64), ("levels", C.c_int32), ("trace_launches", C.c_int32),
-                ("trace_ms", C.c_double), ("frame_ms", C.c_double), ("node_capacity", C.c_int64)]
+                ("trace_ms", C.c_double), ("frame_ms", C.c_double), ("node_capacity", C.c_int64),
+                ("pixels_resampled", C.c_int64), ("aa_samples", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -101,6 +108,9 @@ class FlatScene:
         self.dims = 0
         self.cam_type = 0
         self.cam_focal_distance = 100.0
+        self.cam_aperture_radius = 0.0
+        self.cam_h_fov = 0.0
+        self.cam_v_fov = 0.0
         self.ambient = [0.0, 0.0, 0.0]
         self.background = [0.0, 0.0, 0.0, 1.0]
         self._vecs = []          # list of float
@@ -179,6 +189,11 @@ class FlatScene:
         st.leaf_refs = self.leaf_refs_a.ctypes.data_as(C.POINTER(C.c_int32)); st.n_leaf_refs = len(self.leaf_refs)
         st.inf_refs = self.inf_refs_a.ctypes.data_as(C.POINTER(C.c_int32)); st.n_inf = len(self.inf_refs)
         st.bb_lower_off = self.bb["lower"]; st.bb_upper_off = self.bb["upper"]
+        st.cam_aperture_radius = self.cam_aperture_radius
+        st.cam_h_fov = self.cam_h_fov; st.cam_v_fov = self.cam_v_fov
+        st.cam_left_eye_off = self.cam.get("left_eye", -1); st.cam_right_eye_off = self.cam.get("right_eye", -1)
+        st.cam_local_x_off = self.cam.get("local_x", -1); st.cam_local_y_off = self.cam.get("local_y", -1)
+        st.cam_local_z_off = self.cam.get("local_z", -1)
         self._struct = st
         return self
 
@@ -220,7 +235,8 @@ def load_scene(path):
         return tok
 
     tok = need("ndtscene")
-    if tok[1] != "1":
+    version = tok[1]
+    if version not in ("1", "2"):
         raise ValueError("unsupported ndtscene version " + tok[1])
     tok = need("name"); fs.name = " ".join(tok[1:])
     fs.dims = int(need("dims")[1])
@@ -229,6 +245,12 @@ def load_scene(path):
     fs.cam["img_orig"] = fs.add_vec([_hx(t) for t in need("cam_img_orig")[1:]])
     fs.cam["dir_x"] = fs.add_vec([_hx(t) for t in need("cam_dir_x")[1:]])
     fs.cam["dir_y"] = fs.add_vec([_hx(t) for t in need("cam_dir_y")[1:]])
+    if version == "2":
+        # the rest of the camera: aperture, fields of view, eyes and local axes (camera.h:34-76)
+        tok = need("camera2")
+        fs.cam_aperture_radius = _hx(tok[2]); fs.cam_h_fov = _hx(tok[4]); fs.cam_v_fov = _hx(tok[6])
+        for key in ("left_eye", "right_eye", "local_x", "local_y", "local_z"):
+            fs.cam[key] = fs.add_vec([_hx(t) for t in need("cam_" + key)[1:]])
     fs.ambient = [_hx(t) for t in need("ambient")[1:4]]
     fs.background = [_hx(t) for t in need("background")[1:5]]
     n_lights = int(need("lights")[1])

@@ -117,21 +117,26 @@ class NdtHip:
         self._check(self.lib.ndt_hip_upload_scene(self.ctx, fs.byref()))
         self.scene = fs          # keep the arrays alive; also gives dims
 
-    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
-        return RenderParams(width, height, depth, 1, row_begin, row_step, specular, profile)
+    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
+        p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, profile)
+        if aa is not None:
+            # Whitted's recursive anti-aliasing, `-a diff,depth` (ndt.c:655-733)
+            p.recursive_aa, p.aa_diff, p.aa_depth = 1, int(aa[0]), int(aa[1])
+        return p
 
-    def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
-        """render_image for a row shard; returns ((rows, width, 4) float64 host array, RenderStats)."""
-        p = self.params(width, height, depth, row_begin, row_step, specular, profile)
+    def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
+        """render_image for a row shard; returns ((rows, width, 4) float64 host array, RenderStats).
+        aa = (aa_diff, aa_depth) switches recursive anti-aliasing on."""
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa)
         rows = shard_rows(height, row_begin, row_step)
         out = np.zeros((rows, width, 4), dtype=np.float64)
         st = RenderStats()
         self._check(self.lib.ndt_hip_render(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
         return out, st
 
-    def render_device(self, d_rgba_ptr, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0):
+    def render_device(self, d_rgba_ptr, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
         """Same, output left in HBM at raw device pointer `d_rgba_ptr` (rows*width*4 doubles)."""
-        p = self.params(width, height, depth, row_begin, row_step, specular, profile)
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa)
         st = RenderStats()
         self._check(self.lib.ndt_hip_render_device(self.ctx, C.byref(p), C.c_void_p(d_rgba_ptr), C.byref(st)))
         return st

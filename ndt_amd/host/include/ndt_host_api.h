@@ -385,6 +385,9 @@ int scene_print(scene *scn);
  * width*height*4 doubles laid out like the reference's dbl image (image.c:126).
  * Returns 1 like the reference on success, 0 with a message on stderr otherwise. */
 int ndt_render_image(scene *scn, int width, int height, int threads, int max_optic_depth, double *rgba);
+/* the same with Whitted's recursive anti-aliasing, the reference's `-a diff,depth` (ndt.c:1453-1465); aa_depth < 0 = off */
+int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int max_optic_depth,
+                        double *rgba);
 
 #ifdef __cplusplus
 }

@@ -154,6 +154,15 @@ int ndt_flatten_scene(scene *scn, ndt_flat_builder *fb, char *err, int err_len)
         fs->cam_img_orig_off = push_vec(fb, &scn->cam.imgOrig, dims);
         fs->cam_dir_x_off = push_vec(fb, &scn->cam.dirX, dims);
         fs->cam_dir_y_off = push_vec(fb, &scn->cam.dirY, dims);
+        /* the rest of the camera (ABI 2): depth of field, stereo eyes, VR / panorama axes */
+        fs->cam_aperture_radius = scn->cam.aperture_radius;
+        fs->cam_h_fov = scn->cam.hFov;
+        fs->cam_v_fov = scn->cam.vFov;
+        fs->cam_left_eye_off = push_vec(fb, &scn->cam.leftEye, dims);
+        fs->cam_right_eye_off = push_vec(fb, &scn->cam.rightEye, dims);
+        fs->cam_local_x_off = push_vec(fb, &scn->cam.localX, dims);
+        fs->cam_local_y_off = push_vec(fb, &scn->cam.localY, dims);
+        fs->cam_local_z_off = push_vec(fb, &scn->cam.localZ, dims);
         fs->ambient[0] = scn->ambient.red; fs->ambient[1] = scn->ambient.green; fs->ambient[2] = scn->ambient.blue;
         fs->background[0] = scn->bg_red; fs->background[1] = scn->bg_green; fs->background[2] = scn->bg_blue;
         fs->background[3] = scn->bg_alpha;
@@ -206,12 +215,25 @@ int ndt_write_ndtscene(const ndt_flat_scene *fs, const char *name, const char *p
     FILE *f = fopen(path, "w");
     if (!f) return -1;
     const int d = fs->dims;
-    fprintf(f, "ndtscene 1\nname %s\ndims %d\n", name, d);
+    /* version 2 adds the camera2 block; plain pinhole cameras are written as version 1, the form
+     * the fixtures flattened from the compiled reference have (oracle/ref_shim.c:dump_scene) */
+    const int v2 = (fs->cam_type != 0 || fs->cam_aperture_radius != 0.0 || getenv("NDT_NDTSCENE_V2")) &&
+                   fs->cam_left_eye_off >= 0 && fs->cam_right_eye_off >= 0 && fs->cam_local_x_off >= 0 &&
+                   fs->cam_local_y_off >= 0 && fs->cam_local_z_off >= 0;
+    fprintf(f, "ndtscene %d\nname %s\ndims %d\n", v2 ? 2 : 1, name, d);
     fprintf(f, "camera type %d focal_distance %a\n", fs->cam_type, fs->cam_focal_distance);
     put(f, "cam_pos", fs->vecs + fs->cam_pos_off, d);
     put(f, "cam_img_orig", fs->vecs + fs->cam_img_orig_off, d);
     put(f, "cam_dir_x", fs->vecs + fs->cam_dir_x_off, d);
     put(f, "cam_dir_y", fs->vecs + fs->cam_dir_y_off, d);
+    if (v2) {
+        fprintf(f, "camera2 aperture %a hfov %a vfov %a\n", fs->cam_aperture_radius, fs->cam_h_fov, fs->cam_v_fov);
+        put(f, "cam_left_eye", fs->vecs + fs->cam_left_eye_off, d);
+        put(f, "cam_right_eye", fs->vecs + fs->cam_right_eye_off, d);
+        put(f, "cam_local_x", fs->vecs + fs->cam_local_x_off, d);
+        put(f, "cam_local_y", fs->vecs + fs->cam_local_y_off, d);
+        put(f, "cam_local_z", fs->vecs + fs->cam_local_z_off, d);
+    }
     fprintf(f, "ambient %a %a %a\n", fs->ambient[0], fs->ambient[1], fs->ambient[2]);
     fprintf(f, "background %a %a %a %a\n", fs->background[0], fs->background[1], fs->background[2], fs->background[3]);
     fprintf(f, "lights %d\n", fs->n_lights);

@@ -42,13 +42,21 @@ int main(int argc, char **argv)
 {
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
     int depth = 128, threads = 1;
+    int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
                                         { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
     int ch;
-    while ((ch = getopt_long(argc, argv, "d:r:f:l:s:t:u:o:h", longopts, NULL)) != -1) {
+    while ((ch = getopt_long(argc, argv, "a:d:r:f:l:s:t:u:o:h", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
         switch (ch) {
+        case 'a':       /* -a diff,depth (ndt.c:1453-1465); defaults 20,4 */
+            aa_depth = 4;
+            n = sscanf(optarg, "%d,%d", &a1, &a2);
+            if (n >= 1) aa_diff = a1;
+            if (n >= 2) aa_depth = a2;
+            printf("anti-aliasing = diff=%i,depth=%i\n", aa_diff, aa_depth);
+            break;
         case 'd': dims = atoi(optarg); break;
         case 'r':
             if (!strcmp(optarg, "4k")) { width = 3840; height = 2160; }
@@ -72,7 +80,7 @@ int main(int argc, char **argv)
         case 1001: raw_path = optarg; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+                            "          [-a diff,depth] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -112,7 +120,7 @@ int main(int argc, char **argv)
             continue;
         }
         double t0 = now_s();
-        if (!ndt_render_image(&scn, width, height, threads, depth, rgba)) return 1;
+        if (!ndt_render_image_aa(&scn, width, height, threads, aa_diff, aa_depth, depth, rgba)) return 1;
         printf("rendering took %.3fs\n", now_s() - t0);
         char dir[512], path[1024];
         mkdir("images", 0700);

@@ -6,6 +6,13 @@ static ndt_hip_ctx *g_ctx = NULL;
 
 int ndt_render_image(scene *scn, int width, int height, int threads, int max_optic_depth, double *rgba)
 {
+    return ndt_render_image_aa(scn, width, height, threads, -1, -1, max_optic_depth, rgba);
+}
+
+/* render_image with the reference's `-a diff,depth` (recursive_aa, ndt.c:44, 1039-1087); aa_depth < 0 = plain */
+int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int max_optic_depth,
+                        double *rgba)
+{
     (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
     char err[256];
     ndt_flat_builder fb;
@@ -24,6 +31,11 @@ int ndt_render_image(scene *scn, int width, int height, int threads, int max_opt
         memset(&p, 0, sizeof(p));
         p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = 1;
         p.row_begin = 0; p.row_step = 1; p.specular = 1;
+        if (aa_depth >= 0 && aa_diff < 256) {       /* ndt.c:1040: otherwise the first pass is the image */
+            p.recursive_aa = 1;
+            p.aa_diff = aa_diff;
+            p.aa_depth = aa_depth;
+        }
         if (ndt_hip_render(g_ctx, &p, rgba, NULL) == NDT_OK) ok = 1;
         else fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
     }

@@ -1265,34 +1265,163 @@ typedef struct {
     int thr, threads, literal;
     ray_counts cnt;         /* reference-equivalent counts (times k) */
     ray_counts unique;      /* one sample per pixel */
+    /* recursive anti-aliasing */
+    const double *pass1;    /* (width+1) x n1 rows of corner samples */
+    const int *row_of;      /* image row of every pass-1 row */
+    int n1;
+    long long resampled, aa_samples;
 } job;
 
-/* render_lines_thread / render_line / render_pixel, ndt.c:803 / 735 / 578 (MONO) */
+/* render_pixel (ndt.c:578-653, MONO) + get_pixel_color: the sample at image position (i, j), both in
+ * pixels of a width x height image (fractional for the anti-aliasing samples) */
+static void render_pixel(job *J, tctx *T, int width, int height, double i, double j, pix *clr)
+{
+    double x = i / (double)width - 0.5;
+    double y = -(j / (double)height - 0.5);
+    int k = 0;
+    ray_counts b = T->cnt;
+    get_pixel_color(T, x, y, clr, J->p->max_optic_depth, J->literal, &k);
+    J->unique.primary += (T->cnt.primary - b.primary) / k;
+    J->unique.secondary += (T->cnt.secondary - b.secondary) / k;
+    J->unique.shadow += (T->cnt.shadow - b.shadow) / k;
+}
+
+static void tctx_open(tctx *T, job *J)
+{
+    T->S = J->S;
+    T->mask = (unsigned char *)malloc((size_t)(J->S->n_items > 0 ? J->S->n_items : 1));
+    memset(&T->cnt, 0, sizeof(T->cnt));
+    T->specular = J->p->specular;
+}
+
+/* render_lines_thread / render_line, ndt.c:803 / 735 */
 static void *render_rows(void *arg)
 {
     job *J = (job *)arg;
     const ndt_render_params *p = J->p;
     tctx T;
-    T.S = J->S;
-    T.mask = (unsigned char *)malloc((size_t)(J->S->n_items > 0 ? J->S->n_items : 1));
-    memset(&T.cnt, 0, sizeof(T.cnt));
-    T.specular = p->specular;
+    tctx_open(&T, J);
     int width = p->width, height = p->height;
     int local = 0;
     for (int j = p->row_begin; j < height; j += p->row_step, ++local) {
         if (local % J->threads != J->thr)
             continue;
         for (int i = 0; i < width; ++i) {
-            double x = i / (double)width - 0.5;
-            double y = -(j / (double)height - 0.5);
             pix clr;
-            int k = 0;
-            ray_counts b = T.cnt;
-            get_pixel_color(&T, x, y, &clr, p->max_optic_depth, J->literal, &k);
-            J->unique.primary += (T.cnt.primary - b.primary) / k;
-            J->unique.secondary += (T.cnt.secondary - b.secondary) / k;
-            J->unique.shadow += (T.cnt.shadow - b.shadow) / k;
+            render_pixel(J, &T, width, height, i, j, &clr);
             double *out = J->rgba + ((size_t)local * width + i) * 4;    /* dbl_image_set_pixel, image.c:126 */
+            out[0] = clr.r; out[1] = clr.g; out[2] = clr.b; out[3] = clr.a;
+        }
+    }
+    J->cnt = T.cnt;
+    free(T.mask);
+    return NULL;
+}
+
+/* ---- Whitted's recursive anti-aliasing, ndt.c:655-733 */
+
+/* image_avg_dbl_pixels4, image.c:1175-1197 */
+static void avg4(const pix *p1, const pix *p2, const pix *p3, const pix *p4, pix *avg, double *var)
+{
+    avg->r = (p1->r + p2->r + p3->r + p4->r) / 4;
+    avg->g = (p1->g + p2->g + p3->g + p4->g) / 4;
+    avg->b = (p1->b + p2->b + p3->b + p4->b) / 4;
+    avg->a = (p1->a + p2->a + p3->a + p4->a) / 4;
+    if (var) {
+        double v = 0;
+        v += fabs(avg->r - p1->r) + fabs(avg->r - p2->r) + fabs(avg->r - p3->r) + fabs(avg->r - p4->r);
+        v += fabs(avg->g - p1->g) + fabs(avg->g - p2->g) + fabs(avg->g - p3->g) + fabs(avg->g - p4->g);
+        v += fabs(avg->b - p1->b) + fabs(avg->b - p2->b) + fabs(avg->b - p3->b) + fabs(avg->b - p4->b);
+        v += fabs(avg->a - p1->a) + fabs(avg->a - p2->a) + fabs(avg->a - p3->a) + fabs(avg->a - p4->a);
+        *var = v;
+    }
+}
+
+/* recursive_resample, ndt.c:655-707.  width/height are the first pass's (image + 1). */
+static void recursive_resample(job *J, tctx *T, int width, int height, double x, double y, double step,
+                               const pix *p1, const pix *p2, const pix *p3, const pix *p4, pix *res)
+{
+    const int aa_depth = J->p->aa_depth;
+    pix p5, p6, p7, p8, p9;
+    if (aa_depth <= 0 || step < 1.0 / (2 << (aa_depth - 1))) {
+        avg4(p1, p2, p3, p4, res, NULL);
+        return;
+    }
+    double hs = step / 2;
+    render_pixel(J, T, width, height, x + hs, y + hs, &p5);       /* center */
+    render_pixel(J, T, width, height, x + hs, y, &p6);            /* top middle */
+    render_pixel(J, T, width, height, x, y + hs, &p7);            /* left edge */
+    render_pixel(J, T, width, height, x + step, y + hs, &p8);     /* right edge */
+    render_pixel(J, T, width, height, x + hs, y + step, &p9);     /* bottom middle */
+    J->aa_samples += 5;
+    pix sp1, sp2, sp3, sp4;
+    double var1 = 0, var2 = 0, var3 = 0, var4 = 0;
+    double threshold = J->p->aa_diff / 255.0;
+    avg4(p1, &p6, &p7, &p5, &sp1, &var1);
+    if (var1 > threshold) recursive_resample(J, T, width, height, x, y, hs, p1, &p6, &p7, &p5, &sp1);
+    avg4(p2, &p6, &p8, &p5, &sp2, &var2);
+    if (var2 > threshold) recursive_resample(J, T, width, height, x + hs, y, hs, &p6, p2, &p5, &p8, &sp2);
+    avg4(p3, &p9, &p7, &p5, &sp3, &var3);
+    if (var3 > threshold) recursive_resample(J, T, width, height, x, y + hs, hs, &p7, &p5, p3, &p9, &sp3);
+    avg4(p4, &p9, &p8, &p5, &sp4, &var4);
+    if (var4 > threshold) recursive_resample(J, T, width, height, x + hs, y + hs, hs, &p5, &p8, &p9, p4, &sp4);
+    avg4(&sp1, &sp2, &sp3, &sp4, res, NULL);
+}
+
+/* first pass of the anti-aliased render: rows row_of[0..n1) of the (width+1) x (height+1) corner image */
+static void *render_corner_rows(void *arg)
+{
+    job *J = (job *)arg;
+    const ndt_render_params *p = J->p;
+    tctx T;
+    tctx_open(&T, J);
+    const int w1 = p->width + 1, h1 = p->height + 1;
+    double *img = (double *)J->pass1;
+    for (int r = 0; r < J->n1; ++r) {
+        if (r % J->threads != J->thr)
+            continue;
+        for (int i = 0; i < w1; ++i) {
+            pix clr;
+            render_pixel(J, &T, w1, h1, i, J->row_of[r], &clr);
+            double *out = img + ((size_t)r * w1 + i) * 4;
+            out[0] = clr.r; out[1] = clr.g; out[2] = clr.b; out[3] = clr.a;
+        }
+    }
+    J->cnt = T.cnt;
+    free(T.mask);
+    return NULL;
+}
+
+/* resample_lines_thread / resample_line / resample_pixel, ndt.c:851 / 762 / 709 */
+static void *resample_rows(void *arg)
+{
+    job *J = (job *)arg;
+    const ndt_render_params *p = J->p;
+    tctx T;
+    tctx_open(&T, J);
+    const int width = p->width, height = p->height, w1 = width + 1;
+    int local = 0;
+    for (int j = p->row_begin; j < height; j += p->row_step, ++local) {
+        if (local % J->threads != J->thr)
+            continue;
+        /* pass-1 rows of image rows j and j+1 */
+        int r0 = -1, r1 = -1;
+        for (int r = 0; r < J->n1; ++r) {
+            if (J->row_of[r] == j) r0 = r;
+            if (J->row_of[r] == j + 1) r1 = r;
+        }
+        for (int i = 0; i < width; ++i) {
+            pix c[4], clr;
+            const double *q[4] = { J->pass1 + ((size_t)r0 * w1 + i) * 4, J->pass1 + ((size_t)r0 * w1 + i + 1) * 4,
+                                   J->pass1 + ((size_t)r1 * w1 + i) * 4, J->pass1 + ((size_t)r1 * w1 + i + 1) * 4 };
+            for (int k = 0; k < 4; ++k) { c[k].r = q[k][0]; c[k].g = q[k][1]; c[k].b = q[k][2]; c[k].a = q[k][3]; }
+            double var = 0.0;
+            avg4(&c[0], &c[1], &c[2], &c[3], &clr, &var);
+            if (var > p->aa_diff / 255.0) {
+                J->resampled += 1;
+                recursive_resample(J, &T, width + 1, height + 1, i, j, 1.0, &c[0], &c[1], &c[2], &c[3], &clr);
+            }
+            double *out = J->rgba + ((size_t)local * width + i) * 4;
             out[0] = clr.r; out[1] = clr.g; out[2] = clr.b; out[3] = clr.a;
         }
     }
@@ -1313,7 +1442,22 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     }
     if (p && (p->samples != 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
         return NDT_E_INVALID;
+    if (p && p->stereo != 0) return NDT_E_UNSUPPORTED;
+    /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
+    if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0) return NDT_E_UNSUPPORTED;
     return NDT_OK;
+}
+
+static void run_jobs(job *jobs, int threads, void *(*fn)(void *))
+{
+    pthread_t *thr = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int i = 0; i < threads; ++i) {
+        if (threads > 1) pthread_create(&thr[i], NULL, fn, &jobs[i]);
+        else fn(&jobs[i]);
+    }
+    if (threads > 1)
+        for (int i = 0; i < threads; ++i) pthread_join(thr[i], NULL);
+    free(thr);
 }
 
 /* render_image, ndt.c:900.  flags bit0: literal re-sampling (trace all k samples like the
@@ -1330,30 +1474,51 @@ int ndt_oracle_render(const ndt_flat_scene *fs, const ndt_render_params *p, doub
     if (threads < 1) threads = 1;
     v_scale(S.cam_dir_x, p->width / (double)p->height, S.cam_dir_x, S.n);      /* ndt.c:926 */
     job *jobs = (job *)calloc((size_t)threads, sizeof(job));
-    pthread_t *thr = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
     for (int i = 0; i < threads; ++i) {
         jobs[i].S = &S; jobs[i].p = p; jobs[i].rgba = rgba; jobs[i].thr = i; jobs[i].threads = threads;
         jobs[i].literal = flags & 1;
-        if (threads > 1) pthread_create(&thr[i], NULL, render_rows, &jobs[i]);
-        else render_rows(&jobs[i]);
     }
-    if (threads > 1)
-        for (int i = 0; i < threads; ++i) pthread_join(thr[i], NULL);
+    ray_counts cnt1 = { 0, 0, 0 };
+    double *pass1 = NULL;
+    int *row_of = NULL;
+    if (!p->recursive_aa) {
+        run_jobs(jobs, threads, render_rows);
+    } else {
+        /* first pass (ndt.c:919-976): the corner rows this shard's pixels touch */
+        int n1 = 0;
+        row_of = (int *)malloc(sizeof(int) * (size_t)(2 * p->height + 2));
+        for (int j = p->row_begin; j < p->height; j += p->row_step) {
+            if (n1 == 0 || row_of[n1 - 1] != j) row_of[n1++] = j;
+            row_of[n1++] = j + 1;
+        }
+        pass1 = (double *)calloc((size_t)(n1 > 0 ? n1 : 1) * (size_t)(p->width + 1) * 4, sizeof(double));
+        for (int i = 0; i < threads; ++i) { jobs[i].pass1 = pass1; jobs[i].row_of = row_of; jobs[i].n1 = n1; }
+        run_jobs(jobs, threads, render_corner_rows);
+        for (int i = 0; i < threads; ++i) {
+            cnt1.primary += jobs[i].cnt.primary; cnt1.secondary += jobs[i].cnt.secondary; cnt1.shadow += jobs[i].cnt.shadow;
+        }
+        /* second pass (ndt.c:1039-1087) */
+        run_jobs(jobs, threads, resample_rows);
+    }
     gettimeofday(&t1, NULL);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
+        stats->rays_ref_equiv = cnt1.primary + cnt1.secondary + cnt1.shadow;
         for (int i = 0; i < threads; ++i) {
             stats->rays_primary += jobs[i].unique.primary;
             stats->rays_secondary += jobs[i].unique.secondary;
             stats->rays_shadow += jobs[i].unique.shadow;
             stats->rays_ref_equiv += jobs[i].cnt.primary + jobs[i].cnt.secondary + jobs[i].cnt.shadow;
+            stats->pixels_resampled += jobs[i].resampled;
+            stats->aa_samples += jobs[i].aa_samples;
         }
         stats->frame_ms = 1e3 * ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec));
     }
     free(jobs);
-    free(thr);
+    free(pass1);
+    free(row_of);
     free_scene(&S);
     return NDT_OK;
 }

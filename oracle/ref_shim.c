@@ -11,7 +11,10 @@
  *      reference-side binding for ndt_hip_upload_scene;
  *   2. dumps the double framebuffer render_image produced (via its img_copy argument);
  *   3. answers batches of trace_kd queries (object.c:683) for known-answer tests;
- *   4. counts trace_kd calls (linked with -Wl,--wrap=trace_kd) and times render_image.
+ *   4. counts trace_kd calls (linked with -Wl,--wrap=trace_kd) and times render_image;
+ *   5. --aa diff,depth: runs Whitted's recursive anti-aliasing with the reference's own
+ *      render_line / resample_pixel (ndt.c:735 / 709) and dumps the resampled colours as doubles
+ *      (render_image itself only keeps the 8-bit copy of them, ndt.c:1124).
  * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may run it.
  */
 #define _GNU_SOURCE
@@ -36,6 +39,13 @@ extern int specular_enabled;
 int render_image(scene *scn, char *name, char *depth_name, int width, int height, int samples,
                  int mode, int threads, int aa_diff, int aa_depth, int max_optic_depth,
                  image_t *img_copy, image_t *depth_copy);
+
+/* the anti-aliasing pass's own pieces (ndt.c:44, 709, 735); stereo_mode is an enum, MONO == 0 */
+extern int recursive_aa;
+int render_line(scene *scn, int width, double x_scale, int height, double y_scale, int j, int mode, int samples,
+                image_t *img, image_t *depth_map, int max_optic_depth);
+int resample_pixel(scene *scn, int width, double x_scale, int height, double y_scale, int i, int j, int mode,
+                   int samples, int aa_diff, int aa_depth, image_t *img, dbl_pixel_t *clr, int max_optic_depth);
 
 /* ---- trace_kd call counter (ld --wrap) ---- */
 static long long n_trace_closest = 0;   /* dist_limit < 0 : primary + secondary */
@@ -263,10 +273,11 @@ int main(int argc, char **argv)
     const char *rays_out = arg_str(argc, argv, "--rays-out", NULL);
     const char *tmpdir = arg_str(argc, argv, "--tmp", "/tmp");
     int no_render = arg_flag(argc, argv, "--no-render");
+    const char *aa = arg_str(argc, argv, "--aa", NULL);
     if (!objdir || !scene_so || width < 1 || height < 1) {
         fprintf(stderr, "usage: ndt_ref_shim --objects DIR --scene X.so --dims N [--frame F] [--config S] --res WxH\n"
                         "       [--threads T] [--depth L] [--scene-out F] [--fb-out F] [--rays-in F --rays-out F]\n"
-                        "       [--tmp DIR] [--no-render]\n");
+                        "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH]\n");
         return 2;
     }
 
@@ -333,6 +344,48 @@ int main(int argc, char **argv)
             }
         }
         dump_scene(scene_out, &scn);
+    }
+
+    /* recursive anti-aliasing: first pass of (width+1) x (height+1) corner samples (ndt.c:919-976),
+     * then resample_pixel for every pixel (ndt.c:762-781), single-threaded, in doubles */
+    if (aa) {
+        int aa_diff = 20, aa_depth = 4;
+        sscanf(aa, "%d,%d", &aa_diff, &aa_depth);
+        recursive_aa = 1;
+        image_t img;
+        dbl_image_init(&img);
+        image_set_size(&img, width + 1, height + 1);
+        vectNd_scale(&scn.cam.dirX, width / (double)height, &scn.cam.dirX);      /* ndt.c:926 */
+        n_trace_closest = n_trace_shadow = 0;
+        counting = 1;
+        double t0 = now_s();
+        for (int j = 0; j < height + 1; ++j)
+            render_line(&scn, width + 1, 1.0, height + 1, 1.0, j, 0 /* MONO */, 1, &img, NULL, max_depth);
+        long long rays_pass1 = n_trace_closest + n_trace_shadow;
+        double *out = malloc(sizeof(double) * (size_t)width * height * 4);
+        long long resampled = 0;
+        for (int j = 0; j < height; ++j)
+            for (int i = 0; i < width; ++i) {
+                dbl_pixel_t clr;
+                resampled += resample_pixel(&scn, width, 1.0, height, 1.0, i, j, 0, 1, aa_diff, aa_depth, &img, &clr, max_depth);
+                double *q = out + ((size_t)j * width + i) * 4;
+                q[0] = clr.r; q[1] = clr.g; q[2] = clr.b; q[3] = clr.a;
+            }
+        double t1 = now_s();
+        counting = 0;
+        printf("ref_shim: render_s %.6f threads 1 width %d height %d\n", t1 - t0, width, height);
+        printf("ref_shim: aa_diff %d aa_depth %d pixels_resampled %lld rays_pass1 %lld\n", aa_diff, aa_depth, resampled, rays_pass1);
+        printf("ref_shim: rays_closest %lld rays_shadow %lld rays_total %lld\n", n_trace_closest, n_trace_shadow,
+               n_trace_closest + n_trace_shadow);
+        if (fb_out) {
+            FILE *f = fopen(fb_out, "wb");
+            if (!f) { perror(fb_out); return 2; }
+            fwrite(out, sizeof(double), (size_t)width * height * 4, f);
+            fclose(f);
+        }
+        free(out);
+        image_free(&img);
+        no_render = 1;
     }
 
     /* render (ndt.c:1933).  img_copy is only filled when a file name is given (ndt.c:1024). */

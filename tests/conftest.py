@@ -30,10 +30,13 @@ class Oracle:
         self.lib.ndt_oracle_render.restype = C.c_int
         self.lib.ndt_oracle_trace_rays.restype = C.c_int
 
-    def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1):
+    def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1, aa=None):
+        """aa = (aa_diff, aa_depth) switches Whitted's recursive anti-aliasing on (-a diff,depth)."""
         from ndt_amd import shard_rows
         rows = shard_rows(height, row_begin, row_step)
         p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, 0)
+        if aa is not None:
+            p.recursive_aa, p.aa_diff, p.aa_depth = 1, aa[0], aa[1]
         st = RenderStats()
         out = np.zeros((rows, width, 4), dtype=np.float64)
         threads = threads or min(8, os.cpu_count() or 1)
@@ -96,3 +99,4 @@ SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4
 KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d", "c5_hypercube6d",
              "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d"]
 FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
+AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]

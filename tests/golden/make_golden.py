@@ -62,6 +62,14 @@ CASES = {
                              share_scene="c2_balls4d"),
     "c3_random4d_1080p": dict(scene="random", dims=4, res=(1920, 1080), depth=4, fb=False, rgba8=True, kat=0,
                               share_scene="c3_random4d"),
+    # Whitted's recursive anti-aliasing (-a diff,depth): fb = the resampled image in doubles, produced by the
+    # reference's own render_line + resample_pixel (the shim's --aa mode); reference defaults are 20,4
+    "aa_c3_random4d": dict(scene="random", dims=4, res=(64, 36), depth=4, fb=True, kat=0, aa=(20, 4),
+                           share_scene="c3_random4d"),
+    "aa_c1_hypercube3d": dict(scene="hypercube", dims=3, res=(48, 48), depth=128, fb=True, kat=0, aa=(20, 2),
+                              share_scene="c1_hypercube3d"),
+    "aa_zoo4d": dict(scene="parity_zoo", dims=4, res=(48, 27), depth=6, fb=True, kat=0, aa=(8, 3),
+                     share_scene="zoo4d"),
 }
 
 
@@ -73,6 +81,9 @@ def run_shim(args):
     if m:
         info["ref_render_s"] = float(m.group(1))
         info["ref_threads"] = int(m.group(2))
+    m = re.search(r"ref_shim: aa_diff (\d+) aa_depth (\d+) pixels_resampled (\d+) rays_pass1 (\d+)", out)
+    if m:
+        info["aa_diff"], info["aa_depth"], info["pixels_resampled"], info["rays_pass1"] = (int(m.group(i)) for i in (1, 2, 3, 4))
     m = re.search(r"ref_shim: rays_closest (\d+) rays_shadow (\d+) rays_total (\d+)", out)
     if m:
         info["rays_closest"], info["rays_shadow"], info["rays_total"] = (int(m.group(i)) for i in (1, 2, 3))
@@ -155,6 +166,8 @@ def generate(name, case):
         meta["kd_nodes"] = len(fs.kd_nodes)
         # pass 2: render (+ known answers)
         args = base + ["--tmp", tmp, "--fb-out", os.path.join(tmp, "fb.bin")]
+        if case.get("aa"):
+            args += ["--aa", "%d,%d" % case["aa"]]
         if case["kat"]:
             rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"])
             rays.tofile(os.path.join(tmp, "rays.bin"))

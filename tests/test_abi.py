@@ -32,8 +32,10 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(fsmod.FlatLight) == 16 + 4 * 8
     assert C.sizeof(fsmod.FlatObject) == 14 * 4 + 8 * 8
     assert C.sizeof(fsmod.FlatKdNode) == 32
-    assert C.sizeof(fsmod.RenderParams) == 32
-    assert C.sizeof(fsmod.RenderStats) == 4 * 8 + 2 * 4 + 3 * 8
+    assert C.sizeof(fsmod.RenderParams) == 16 * 4
+    assert C.sizeof(fsmod.RenderStats) == 4 * 8 + 2 * 4 + 3 * 8 + 2 * 8
+    # the library and the binding agree on the ABI revision the flat scene carries
+    assert nh.load_library().ndt_hip_abi_version() == fsmod.ABI_VERSION == 2
 
 
 def test_shard_rows_helper_agrees_with_library():

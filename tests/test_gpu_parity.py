@@ -9,7 +9,7 @@ may differ in the last ulps, hence TOL_TIGHT is what we actually expect and TOL_
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -147,3 +147,44 @@ def test_bad_scene_is_rejected_not_rendered(gpu):
     finally:
         st.cam_type = old
     gpu.upload_scene(g.scene)
+
+
+@pytest.mark.parametrize("name", AA_CASES)
+def test_recursive_antialiasing_vs_reference(gpu, name):
+    """Whitted's recursive anti-aliasing (-a diff,depth): the device walks the recursion tree level
+    by level; the resampled image, the number of resampled pixels and the reference's trace_kd
+    count must come out the same."""
+    g = golden(name)
+    aa = (g.meta["aa_diff"], g.meta["aa_depth"])
+    gpu.upload_scene(g.scene)
+    out, st = gpu.render(g.width, g.height, g.depth, aa=aa)
+    ref = g.data["fb"]
+    diff = np.abs(out - ref)
+    assert diff.max() < TOL_TIGHT, "max abs diff %g" % diff.max()
+    assert st.pixels_resampled == g.meta["pixels_resampled"]
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+def test_recursive_antialiasing_row_shards_and_oracle(gpu, oracle):
+    g = golden("aa_zoo4d")
+    gpu.upload_scene(g.scene)
+    aa = (12, 2)
+    w, h = g.width + 5, g.height + 2
+    want, so = oracle.render(g.scene, w, h, g.depth, aa=aa)
+    full, st = gpu.render(w, h, g.depth, aa=aa)
+    assert np.abs(full - want).max() < TOL_TIGHT
+    assert (st.pixels_resampled, st.aa_samples, st.rays_ref_equiv) == (so.pixels_resampled, so.aa_samples, so.rays_ref_equiv)
+    for begin in range(3):
+        part, _ = gpu.render(w, h, g.depth, row_begin=begin, row_step=3, aa=aa)
+        assert np.array_equal(part, full[begin::3])
+
+
+def test_antialiasing_cutoffs(gpu, oracle):
+    """aa_depth 0 (the recursion's cut-off at the first call) and a threshold nothing exceeds."""
+    g = golden("aa_c1_hypercube3d")
+    gpu.upload_scene(g.scene)
+    for aa in ((20, 0), (255 * 8, 3)):
+        want, so = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa)
+        out, st = gpu.render(g.width, g.height, g.depth, aa=aa)
+        assert np.abs(out - want).max() < TOL_TIGHT
+        assert st.pixels_resampled == so.pixels_resampled

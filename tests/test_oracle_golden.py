@@ -7,7 +7,7 @@ same glibc libm, no FMA, SSE lane-pair dot order.
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -66,3 +66,25 @@ def test_row_sharding_matches_full_frame(oracle):
         for begin in range(step):
             part, _ = oracle.render(g.scene, g.width, g.height, g.depth, row_begin=begin, row_step=step)
             assert np.array_equal(part, full[begin::step])
+
+
+@pytest.mark.parametrize("name", AA_CASES)
+def test_recursive_antialiasing_bit_exact(oracle, name):
+    """Whitted's recursive anti-aliasing (-a diff,depth; ndt.c:655-733): the resampled image of the
+    reference's own render_line + resample_pixel, its "pixels resampled" count and its trace_kd count."""
+    g = golden(name)
+    aa = (g.meta["aa_diff"], g.meta["aa_depth"])
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa)
+    ref = g.data["fb"]
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    assert st.pixels_resampled == g.meta["pixels_resampled"] > 0
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+def test_recursive_antialiasing_row_shards(oracle):
+    g = golden("aa_zoo4d")
+    aa = (g.meta["aa_diff"], g.meta["aa_depth"])
+    full = g.data["fb"]
+    for begin in range(3):
+        part, _ = oracle.render(g.scene, g.width, g.height, g.depth, row_begin=begin, row_step=3, aa=aa)
+        assert np.array_equal(part, full[begin::3])
