@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,11 @@ struct ndt_hip_ctx {
     size_t d_out_bytes = 0;
     int *h_counters = nullptr;      // pinned
     LevelRange *h_levels = nullptr; // pinned, NDT_MAX_LEVELS + 1
+    LevelRange *h_mail = nullptr;   // mapped + coherent: bounce ranges posted by k_level_step while the frame runs
+    unsigned long long *h_mail_tag = nullptr;
+    LevelRange *d_mail = nullptr;   // the device's view of the two
+    unsigned long long *d_mail_tag = nullptr;
+    unsigned long long frame_tag = 0;
     unsigned long long *h_ref = nullptr;   // pinned, 64 x 8
     std::vector<hipEvent_t> ev_pool;
 };
@@ -131,6 +137,11 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     }
     e = hipHostMalloc((void **)&ctx->h_counters, 128 * sizeof(int), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_levels, (NDT_MAX_LEVELS + 1) * sizeof(LevelRange), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_mail, (NDT_MAX_LEVELS + 2) * sizeof(LevelRange), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_mail_tag, (NDT_MAX_LEVELS + 2) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail_tag, ctx->h_mail_tag, 0);
+    if (e == hipSuccess) memset(ctx->h_mail_tag, 0, (NDT_MAX_LEVELS + 2) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -167,6 +178,8 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_levels) (void)hipHostFree(ctx->h_levels);
+    if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+    if (ctx->h_mail_tag) (void)hipHostFree(ctx->h_mail_tag);
     if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
@@ -924,8 +937,10 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
 
 // After shade_emit(level) has spawned the next bounce: publish its range, note the shadow rays
 // this bounce emitted, and clear the other parity's segment counters for the next shade_emit.
-// One wavefront.
-__global__ void k_level_step(Workspace ws, int level, int n_seg)
+// The range is also posted to host-visible memory: k_level_step runs early in a bounce (before
+// its long trace launch), so by the time the host wants to enqueue the next bounce the answer
+// is there and the GPU never waits for the host.  One wavefront.
+__global__ void k_level_step(Workspace ws, int level, int n_seg, unsigned long long tag)
 {
     const int lane = threadIdx.x;
     int *seg = NDT_SEG_COUNTERS(ws, level);
@@ -950,6 +965,10 @@ __global__ void k_level_step(Workspace ws, int level, int n_seg)
         next.seg_stride = 0;
     }
     ws.levels[level + 1] = next;
+    // ... and for the host, which enqueues bounce level+1 only once it knows there is one
+    ws.mail[level + 1] = next;
+    __threadfence_system();
+    __hip_atomic_store(&ws.mail_tag[level + 1], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Bottom-up combine of one bounce: get_ray_color's blend of its own colour with the colours
@@ -1092,6 +1111,13 @@ static hipEvent_t get_event(ndt_hip_ctx *ctx, size_t idx)
     return ctx->ev_pool[idx];
 }
 
+static double wall_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 // One pass of the ray pipeline over the primaries `rg` describes: primary rays, the bounce loop,
 // bottom-up resolve, per-primary colour (k_finish_pixels) into d_rgba.  Grid mode writes a
 // rows x width image, list mode one RGBA per sample.  max_depth > 0 (the callers handle -l 0).
@@ -1127,8 +1153,12 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         HIP_TRY(hipMemsetAsync(ws.dbg, 0, 64 * sizeof(unsigned long long), s));
         // work-queue heads of every launch of the frame + both parities of the shadow-segment counters
         HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)(NDT_CNT_TOTAL - NDT_CNT_QUEUE) * sizeof(int), s));
-        // The whole frame is enqueued without reading anything back: the range of every bounce
-        // is published on the device (k_level_step) and read there.  Bounce 0 = the primaries.
+        // The stream is never synchronised inside a frame: the range of every bounce is published
+        // on the device (k_level_step) and read there; the host only learns, from the mailbox,
+        // whether there is a next bounce to enqueue.  Bounce 0 = the primaries.
+        ws.mail = ctx->d_mail;
+        ws.mail_tag = ctx->d_mail_tag;
+        const unsigned long long tag = ++ctx->frame_tag;
         const int n_seg = ctx->n_shadow_lights;
         const int n_levels = rg.max_depth > 1 ? rg.max_depth : 1;      // a node spawns children only while depth_left > 1
         int n_run = n_levels;                                           // bounces actually enqueued
@@ -1169,15 +1199,31 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             tj.begin = 0; tj.count = rg.n_primary; tj.levels = nullptr;
             if ((rc = traced(tj, "closest 0"))) return rc;
         }
-        long long upper = rg.n_primary;         // bound on the node count of the bounce (each node spawns at most two)
+        long long upper = rg.n_primary;         // node count of the bounce
+        std::vector<long long> level_nodes;
         for (int b = 0; b < n_levels; ++b) {
             if (queue_slot + 1 > NDT_QUEUE_SLOTS || b + 1 > NDT_MAX_LEVELS)
                 return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
-            if (upper > ws.cap) upper = ws.cap;
+            if (b > 0) {
+                // posted by k_level_step(b-1), which ran right after shade_emit(b-1)
+                const double t_wait = wall_s();
+                while (__atomic_load_n(&ctx->h_mail_tag[b], __ATOMIC_ACQUIRE) != tag) {
+                    if (wall_s() - t_wait > 30.0) {
+                        HIP_TRY(hipStreamSynchronize(s));
+                        if (__atomic_load_n(&ctx->h_mail_tag[b], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "bounce %d was never published", b);
+                    }
+                }
+                upper = ctx->h_mail[b].count;
+                if (upper <= 0) {
+                    n_run = b;
+                    break;
+                }
+            }
+            level_nodes.push_back(upper);
             // hit points, shadow rays of this bounce, and the rays of the next bounce
             kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
-            hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg);
-            long long next_upper = 2 * upper;
+            hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
+            long long next_upper = 2 * upper;           // each node spawns at most two
             if (next_upper > ws.cap) next_upper = ws.cap;
             {
                 // ONE launch: shadow rays of bounce b + closest-hit rays of bounce b+1
@@ -1195,27 +1241,11 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                 if ((rc = traced(tj, "shadow " + std::to_string(b) + " + closest " + std::to_string(b + 1)))) return rc;
             }
             kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
-            upper = next_upper;
-            // deep recursion limits (-l 50): look every 8 bounces whether the tree has died out
-            if ((b & 7) == 7 && b + 1 < n_levels) {
-                HIP_TRY(hipMemcpyAsync(hl + b + 1, ws.levels + b + 1, sizeof(LevelRange), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if (hl[b + 1].count <= 0) {
-                    n_run = b + 1;
-                    break;
-                }
-            }
         }
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
-            std::vector<long long> ub((size_t)n_run);
-            long long u = rg.n_primary;
-            for (int b = 0; b < n_run; ++b) {
-                ub[b] = u > ws.cap ? ws.cap : u;
-                u = 2 * ub[b];
-            }
             for (int b = n_run; b-- > 0;) {
-                long long blocks = (ub[b] + 255) / 256;
+                long long blocks = (level_nodes[b] + 255) / 256;
                 if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
                 hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws, rg.specular, b);
             }

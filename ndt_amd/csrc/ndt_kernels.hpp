@@ -45,6 +45,10 @@ struct Workspace {
     long long mask_slab_lanes;
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
     LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
+    // the same table in host-visible (mapped, coherent) memory + one tag per entry: k_level_step
+    // posts bounce b+1 here, the host polls the tag instead of synchronising the stream
+    LevelRange *mail;
+    unsigned long long *mail_tag;
 };
 
 // What the primary rays of one pass are.  Grid mode: the pixels of `rows` image rows of a
