@@ -368,6 +368,7 @@ typedef struct scene_t {
 
 int scene_init(scene *scn, char *name, int dim);
 int scene_free(scene *scn);
+int scene_add_object(scene *scn, object *obj);
 int scene_alloc_object(scene *scn, int dimensions, object **obj, char *type);
 int scene_remove_object(scene *scn, object *obj);
 int scene_alloc_light(scene *scn, light **lgt);
@@ -376,6 +377,10 @@ int scene_aim_light(light *lgt, vectNd *target);
 int scene_prepare_light(light *lgt);
 int scene_validate_objects(scene *scn);
 int scene_print(scene *scn);
+/* YAML scene files (scene.h:80-86; scene.c:573-2177): one `---` document per animation frame */
+int scene_write_yaml(scene *scn, char *fname);
+int scene_read_yaml(scene *scn, char *fname, int frame);
+int scene_yaml_count_frames(char *fname);
 
 /* ------------------------------------------------------------------ the accelerated entry */
 

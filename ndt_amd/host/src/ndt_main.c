@@ -38,6 +38,25 @@ static int write_ppm(const char *path, const double *rgba, int w, int h)
     return 0;
 }
 
+/* scenes/yaml.c:14-50 */
+static int yaml_scene_frames(int dimensions, char *config)
+{
+    if (config == NULL || dimensions < 3) return 0;
+    return scene_yaml_count_frames(config);
+}
+
+static int yaml_scene_setup(scene *scn, int dimensions, int frame, int frames, char *config)
+{
+    (void)frames;
+    scene_init(scn, "nameless", dimensions);
+    if (config == NULL) {
+        fprintf(stderr, "YAML scene requires a filename, use `-u filename`.\n");
+        exit(1);
+    }
+    scene_read_yaml(scn, config, frame);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
@@ -79,7 +98,7 @@ int main(int argc, char **argv)
         case 1000: dump_path = optarg; break;
         case 1001: raw_path = optarg; break;
         default:
-            fprintf(stderr, "usage: %s -s scene.so [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
+            fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
                             "          [-a diff,depth] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
@@ -88,14 +107,20 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s: need -s scene.so, dims >= 3 and a resolution\n", argv[0]);
         return 1;
     }
-    void *dl = dlopen(scene_path, RTLD_NOW);
-    if (!dl) { fprintf(stderr, "%s\n", dlerror()); return 1; }
     int (*setup)(scene *, int, int, int, char *) = NULL;
     int (*frame_count)(int, char *) = NULL;
     int (*cleanup)(void) = NULL;
-    *(void **)(&setup) = dlsym(dl, "scene_setup");
-    *(void **)(&frame_count) = dlsym(dl, "scene_frames");
-    *(void **)(&cleanup) = dlsym(dl, "scene_cleanup");
+    if (!strcmp(scene_path, "builtin:yaml")) {
+        /* the reference's scenes/yaml.c, built in: -u names the YAML file, one document per frame */
+        setup = yaml_scene_setup;
+        frame_count = yaml_scene_frames;
+    } else {
+        void *dl = dlopen(scene_path, RTLD_NOW);
+        if (!dl) { fprintf(stderr, "%s\n", dlerror()); return 1; }
+        *(void **)(&setup) = dlsym(dl, "scene_setup");
+        *(void **)(&frame_count) = dlsym(dl, "scene_frames");
+        *(void **)(&cleanup) = dlsym(dl, "scene_cleanup");
+    }
     if (!setup) { fprintf(stderr, "%s has no scene_setup\n", scene_path); return 1; }
     if (frame_count && !frames_given) frames = frame_count(dims, config);
     if (last < 0) last = frames - 1;

@@ -43,14 +43,21 @@ int scene_free(scene *scn)
     return 1;
 }
 
+/* scene.c:62-75 */
+int scene_add_object(scene *scn, object *obj)
+{
+    object **grown = (object **)realloc(scn->object_ptrs, ((size_t)scn->num_objects + 1) * sizeof(object *));
+    if (!grown) return 0;
+    scn->object_ptrs = grown;
+    scn->object_ptrs[scn->num_objects++] = obj;
+    return 1;
+}
+
 int scene_alloc_object(scene *scn, int dimensions, object **obj, char *type)
 {
     *obj = object_alloc(dimensions, type, "unnamed");
     if (!*obj) return 0;
-    object **grown = (object **)realloc(scn->object_ptrs, ((size_t)scn->num_objects + 1) * sizeof(object *));
-    if (!grown) { free(*obj); *obj = NULL; return 0; }
-    scn->object_ptrs = grown;
-    scn->object_ptrs[scn->num_objects++] = *obj;
+    if (!scene_add_object(scn, *obj)) { free(*obj); *obj = NULL; return 0; }
     return 1;
 }
 

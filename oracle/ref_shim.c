@@ -274,10 +274,11 @@ int main(int argc, char **argv)
     const char *tmpdir = arg_str(argc, argv, "--tmp", "/tmp");
     int no_render = arg_flag(argc, argv, "--no-render");
     const char *aa = arg_str(argc, argv, "--aa", NULL);
+    const char *yaml_out = arg_str(argc, argv, "--yaml-out", NULL);
     if (!objdir || !scene_so || width < 1 || height < 1) {
         fprintf(stderr, "usage: ndt_ref_shim --objects DIR --scene X.so --dims N [--frame F] [--config S] --res WxH\n"
                         "       [--threads T] [--depth L] [--scene-out F] [--fb-out F] [--rays-in F --rays-out F]\n"
-                        "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH]\n");
+                        "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH] [--yaml-out F]\n");
         return 2;
     }
 
@@ -309,6 +310,7 @@ int main(int argc, char **argv)
         if (i < frame) scene_free(&scn);
     }
     printf("ref_shim: scene '%s' %d objects %d lights\n", scn.name, scn.num_objects, scn.num_lights);
+    if (yaml_out) scene_write_yaml(&scn, (char *)yaml_out);       /* what `ndt -y` writes per frame (ndt.c:1798-1809) */
 
     /* kd-tree build, as ndt.c:1899-1908 */
     kd_tree_init(&kdtree, scn.dimensions);

@@ -191,12 +191,69 @@ def generate(name, case):
     print("   ", {k: v for k, v in meta.items() if k.startswith("rays") or k.startswith("ref_")}, flush=True)
 
 
+# YAML scene files (`ndt -y` writes them, `-s scenes/yaml.so -u file.yaml` reads them; scene.c:573-2177).
+# name -> the frames of which scene program the reference writes into one file (one document per
+# frame), and which document it then loads back through its own scenes/yaml.so.  Stored under
+# tests/golden/yaml/: <name>.yaml.gz (what the reference wrote) and <name>.ndtscene.gz (the scene
+# the reference built from it, flattened) (+ <name>.npz with the framebuffer it rendered, if asked).
+YAML_CASES = {
+    "y_random4d": dict(scene="random", dims=4, frames=[0], load=0, render=(64, 36), depth=4),
+    "y_hypercube3d_2frames": dict(scene="hypercube", dims=3, frames=[0, 37], load=1),
+    "y_balls4d": dict(scene="balls", dims=4, frames=[0], load=0),
+    "y_zoo5d": dict(scene="parity_zoo", dims=5, frames=[2], load=0),
+    "y_zoo3d_mirror": dict(scene="parity_zoo", dims=3, frames=[0], load=0, config="mirror"),
+    "y_hypercube6d": dict(scene="hypercube", dims=6, frames=[0], load=0),
+}
+
+
+def generate_yaml(name, case):
+    print("==", name, flush=True)
+    out_dir = os.path.join(HERE, "yaml")
+    os.makedirs(out_dir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        text = ""
+        for fr in case["frames"]:
+            part = os.path.join(tmp, "f%d.yaml" % fr)
+            args = ["--scene", os.path.join(REF, "scenes", case["scene"] + ".so"), "--dims", str(case["dims"]),
+                    "--frame", str(fr), "--res", "8x8", "--no-render", "--yaml-out", part, "--tmp", tmp]
+            if case.get("config"):
+                args += ["--config", case["config"]]
+            run_shim(args)
+            text += open(part).read()
+        yaml_path = os.path.join(tmp, name + ".yaml")
+        with open(yaml_path, "w") as f:
+            f.write(text)
+        scene_txt = os.path.join(tmp, "scene.txt")
+        base = ["--scene", os.path.join(REF, "scenes", "yaml.so"), "--config", yaml_path, "--dims", str(case["dims"]),
+                "--frame", str(case["load"]), "--tmp", tmp]
+        run_shim(base + ["--res", "8x8", "--no-render", "--scene-out", scene_txt])
+        for src, dst in ((yaml_path, name + ".yaml.gz"), (scene_txt, name + ".ndtscene.gz")):
+            with open(src, "rb") as fi, open(os.path.join(out_dir, dst), "wb") as raw:
+                with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as fo:
+                    fo.write(fi.read())
+        meta = dict(name=name, scene=case["scene"], dims=case["dims"], frames_written=case["frames"], frame_loaded=case["load"],
+                    config=case.get("config"), generator="tests/golden/make_golden.py via oracle/ref_shim.c")
+        if case.get("render"):
+            w, h = case["render"]
+            info = run_shim(base + ["--res", "%dx%d" % (w, h), "--depth", str(case["depth"]), "--threads", str(os.cpu_count() or 1),
+                                    "--fb-out", os.path.join(tmp, "fb.bin")])
+            meta.update(info)
+            meta.update(width=w, height=h, depth=case["depth"])
+            np.savez_compressed(os.path.join(out_dir, name + ".npz"), fb=np.fromfile(os.path.join(tmp, "fb.bin")).reshape(h, w, 4))
+        with open(os.path.join(out_dir, name + ".json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+            f.write("\n")
+
+
 def main():
     if not os.path.exists(SHIM):
         raise SystemExit("build the reference first: make -C oracle ref")
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(YAML_CASES))
     for name in names:
-        generate(name, CASES[name])
+        if name in YAML_CASES:
+            generate_yaml(name, YAML_CASES[name])
+        else:
+            generate(name, CASES[name])
 
 
 if __name__ == "__main__":
