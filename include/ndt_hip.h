@@ -172,7 +172,7 @@ typedef struct ndt_render_params {
     int32_t recursive_aa;       /* 0 = off */
     int32_t aa_diff;            /* reference default 20 (ndt.c:1412) */
     int32_t aa_depth;           /* reference default 4 (ndt.c:1411) */
-    int32_t stereo;             /* ndt_stereo_mode; only NDT_STEREO_MONO so far */
+    int32_t stereo;             /* ndt_stereo_mode (needs the eyes in the flat scene); not with recursive_aa */
     int32_t reserved[4];        /* must be 0 */
 } ndt_render_params;
 
@@ -192,6 +192,13 @@ typedef struct ndt_render_stats {
     int64_t aa_samples;         /* recursive AA: extra get_pixel_color samples rendered by the second pass */
 } ndt_render_stats;
 
+/* stereo_mode (ndt.c:46-48).  SIDE_SIDE / OVER_UNDER put the left-eye image in the left / top half and
+ * the right-eye image in the other (each squeezed to half size), ANAGLYPH mixes the luminance of the
+ * two eyes into red and blue (ndt.c:590-650).  HIDEF_3D (frame-packed 1080p) is not implemented. */
+enum ndt_stereo_mode {
+    NDT_STEREO_MONO = 0, NDT_STEREO_SIDE_SIDE = 1, NDT_STEREO_OVER_UNDER = 2, NDT_STEREO_ANAGLYPH = 3, NDT_STEREO_HIDEF = 4
+};
+
 typedef struct ndt_hip_ctx ndt_hip_ctx;
 
 /* Create a context on HIP device `device` with its own stream.  Fails with NDT_E_DEVICE when
@@ -210,6 +217,13 @@ int ndt_hip_upload_scene(ndt_hip_ctx *ctx, const ndt_flat_scene *scene);
  * plain: `rgba` is host memory. */
 int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats);
 int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, ndt_render_stats *stats);
+
+/* The same with the depth map render_image fills when it is given a depth file name (ndt.c:930-935,
+ * 753-756): `depth` receives rows*width doubles, 1/distance of the primary hit (the left eye's for
+ * ANAGLYPH), 0 where the primary ray misses.  Not with recursive_aa.  (The reference leaves the
+ * previous pixel's value when the hit lies within EPSILON of the eye; this library writes 0.) */
+int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, void *d_depth, ndt_render_stats *stats);
+int ndt_hip_render_depth(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, double *depth, ndt_render_stats *stats);
 
 /* Batch of trace_kd queries (object.c:683) against the uploaded scene -- the unit the
  * known-answer tests pin.  o, v: n*dims doubles (ray-major); dist_limit: n doubles with the

@@ -75,6 +75,8 @@ struct ndt_hip_ctx {
     int dims = 0;
     bool have_scene = false;
     double aperture_radius = 0.0;   // camera.h:46 of the uploaded scene
+    int cam_type = 0;
+    bool have_eyes = false, have_local_axes = false;
     SceneDesc sd{};
     std::vector<double> blob;
     double *d_blob = nullptr;
@@ -824,6 +826,23 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     b.push(fs->cam_focal_distance);
     for (int i = 0; i < 3; ++i) b.push(fs->ambient[i]);
     for (int i = 0; i < 4; ++i) b.push(fs->background[i]);
+    // the rest of the camera, at off_cam + 4N + 8: type, hFov, vFov, leftEye, rightEye, localX, localY, localZ
+    // (camera.h:34-75; zeros where the scene does not carry them -- ndt_hip_render checks before use)
+    {
+        const int32_t offs[5] = { fs->cam_left_eye_off, fs->cam_right_eye_off, fs->cam_local_x_off, fs->cam_local_y_off,
+                                  fs->cam_local_z_off };
+        b.push((double)fs->cam_type);
+        b.push(fs->cam_h_fov);
+        b.push(fs->cam_v_fov);
+        for (int k = 0; k < 5; ++k) {
+            if (offs[k] >= 0 && !vec_ok(fs, offs[k], 1)) return fail(NDT_E_INVALID, "camera vectors out of range");
+            if (offs[k] >= 0) b.push_vec(fs->vecs + offs[k], n);
+            else for (int c = 0; c < n; ++c) b.push(0.0);
+        }
+        ctx->cam_type = fs->cam_type;
+        ctx->have_eyes = offs[0] >= 0 && offs[1] >= 0;
+        ctx->have_local_axes = offs[2] >= 0 && offs[3] >= 0 && offs[4] >= 0;
+    }
     sd.total_words = b.words();
 
     ctx->sd = sd;
@@ -841,7 +860,9 @@ extern "C" int ndt_hip_upload_scene(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     if (fs->abi_version != NDT_HIP_ABI_VERSION) return fail(NDT_E_INVALID, "scene ABI %d, library ABI %d", fs->abi_version, NDT_HIP_ABI_VERSION);
     if (fs->dims < NDT_MIN_DIMS || fs->dims > NDT_MAX_DIMS)
         return fail(NDT_E_UNSUPPORTED, "%d dimensions: kernels are built for %d..%d", fs->dims, NDT_MIN_DIMS, NDT_MAX_DIMS);
-    if (fs->cam_type != 0) return fail(NDT_E_UNSUPPORTED, "camera type %d: only CAMERA_NORMAL (camera.c:557) is on the device path", fs->cam_type);
+    if (fs->cam_type < 0 || fs->cam_type > 2) return fail(NDT_E_UNSUPPORTED, "camera type %d", fs->cam_type);
+    if (fs->cam_type != 0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0 || fs->cam_local_z_off < 0))
+        return fail(NDT_E_INVALID, "VR / panorama cameras need the local axes (camera.h:69-71) in the flat scene");
     if (fs->n_lights < 0 || fs->n_lights > NDT_MAX_LIGHTS) return fail(NDT_E_UNSUPPORTED, "%d lights (max %d)", fs->n_lights, NDT_MAX_LIGHTS);
     if (fs->n_objects < 0 || fs->n_items < 0 || fs->n_items > fs->n_objects) return fail(NDT_E_INVALID, "object counts");
     if (fs->n_kd_nodes < 0 || fs->n_inf < 0 || fs->n_leaf_refs < 0) return fail(NDT_E_INVALID, "kd-tree counts");
@@ -903,6 +924,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.ray_o, (size_t)n * cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.depth, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return rc;
@@ -1020,7 +1042,7 @@ __global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc s
 // with samples == 1 the reference re-traces the identical ray k times, k decided by the
 // running-mean test below; the result is (c+...+c)/k and the k-fold ray count.
 __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
-                                                       double *rgba)
+                                                       double *rgba, double *depth_out)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long weighted = 0ull;
@@ -1072,6 +1094,7 @@ __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, Scene
         out[1] = t[1] / samples;
         out[2] = t[2] / samples;
         out[3] = t[3] / samples;
+        if (depth_out) depth_out[out_idx] = ws.depth[g];       // ndt.c:753-756
         weighted = (unsigned long long)samples * (unsigned long long)ws.count[g];
     }
     // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
@@ -1121,8 +1144,9 @@ static double wall_s()
 // One pass of the ray pipeline over the primaries `rg` describes: primary rays, the bounce loop,
 // bottom-up resolve, per-primary colour (k_finish_pixels) into d_rgba.  Grid mode writes a
 // rows x width image, list mode one RGBA per sample.  max_depth > 0 (the callers handle -l 0).
-static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st)
+static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth = nullptr)
 {
+    rg.want_depth = d_depth ? 1 : 0;
     hipStream_t s = ctx->stream;
     const long long n_primary = rg.n_primary;
     const long long n_pixels = rg.samples ? (long long)rg.n_samples : (long long)rg.rows * rg.width;
@@ -1251,7 +1275,7 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             }
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
-                           rg, ctx->dims, (double *)d_rgba);
+                           rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
         HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
         unsigned long long ref_rays = 0;
@@ -1501,6 +1525,7 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
     g1.img_h = H + 1;
     g1.aspect_w = W;
     g1.aspect_h = H;
+    g1.eye = 1;
     double *pass1 = nullptr;
     if ((rc = buf.get(&pass1, (size_t)g1.rows * g1.width * 4))) return rc;
     ndt_render_stats st{};
@@ -1553,6 +1578,7 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
         gs.img_h = H + 1;
         gs.aspect_w = W;
         gs.aspect_h = H;
+        gs.eye = 1;
         if ((rc = render_pass(ctx, gs, prof, colours, st))) return rc;
         add_stats(total, st);
         total.aa_samples += gs.n_samples;
@@ -1578,18 +1604,35 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
     return NDT_OK;
 }
 
-extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats)
+// true anaglyph (ndt.c:643-647): red = luminance of the left eye's colour, blue = of the right eye's
+__global__ void k_anaglyph(const double *left, const double *right, double *out, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const double *l = left + 4 * i, *r = right + 4 * i;
+    out[4 * i + 0] = 0.299 * l[0] + 0.587 * l[1] + 0.114 * l[2];
+    out[4 * i + 1] = 0;
+    out[4 * i + 2] = 0.299 * r[0] + 0.587 * r[1] + 0.114 * r[2];
+    out[4 * i + 3] = 1.0;
+}
+
+extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, void *d_depth,
+                                           ndt_render_stats *stats)
 {
     if (!ctx || !p || !d_rgba) return fail(NDT_E_INVALID, "NULL argument");
     if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
     if (p->samples != 1) return fail(NDT_E_UNSUPPORTED, "samples=%d: only the deterministic samples=1 path is implemented", p->samples);
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
-    if (p->stereo != 0) return fail(NDT_E_UNSUPPORTED, "stereo mode %d: only mono is implemented", p->stereo);
+    if (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)
+        return fail(NDT_E_UNSUPPORTED, "stereo mode %d (mono, side by side, over/under and anaglyph are implemented)", p->stereo);
+    if (p->stereo != NDT_STEREO_MONO && !ctx->have_eyes) return fail(NDT_E_INVALID, "stereo needs leftEye / rightEye (camera.h:60-61) in the flat scene");
     for (int k = 0; k < 4; ++k)
         if (p->reserved[k] != 0) return fail(NDT_E_INVALID, "reserved render parameter set");
     if (p->recursive_aa && ctx->aperture_radius != 0.0)
         return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing with aperture radius %g samples the lens with drand48 (ndt.c:528): not reproducible", ctx->aperture_radius);
     if (p->recursive_aa && (p->aa_diff < 0 || p->aa_depth > 24)) return fail(NDT_E_INVALID, "bad anti-aliasing parameters");
+    if (p->recursive_aa && (p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
+        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing is implemented for the mono planar camera without a depth map");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
@@ -1602,6 +1645,7 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
     if (p->max_optic_depth <= 0) {
         // get_ray_color returns black without tracing (ndt.c:340); averages of black are black
         hipLaunchKernelGGL(k_fill_black, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, (double *)d_rgba, n_pixels);
+        if (d_depth) HIP_TRY(hipMemsetAsync(d_depth, 0, (size_t)n_pixels * sizeof(double), s));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));
         if (stats) *stats = st;
@@ -1629,20 +1673,52 @@ extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *
         rg.img_h = p->height;
         rg.aspect_w = p->width;
         rg.aspect_h = p->height;
-        rc = render_pass(ctx, rg, p->profile != 0, d_rgba, st);
+        rg.eye = 1;
+        if (p->stereo == NDT_STEREO_ANAGLYPH) {
+            // two full renders, one per eye (ndt.c:636-647); the depth map is the left eye's
+            AaBuffers buf;
+            double *left = nullptr, *right = nullptr;
+            if ((rc = buf.get(&left, (size_t)n_pixels * 4))) return rc;
+            if ((rc = buf.get(&right, (size_t)n_pixels * 4))) return rc;
+            ndt_render_stats one{};
+            rg.eye = 0;
+            if ((rc = render_pass(ctx, rg, p->profile != 0, left, one, d_depth))) return rc;
+            add_stats(st, one);
+            rg.eye = 2;
+            if ((rc = render_pass(ctx, rg, p->profile != 0, right, one))) return rc;
+            add_stats(st, one);
+            hipLaunchKernelGGL(k_anaglyph, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, left, right, (double *)d_rgba, n_pixels);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            rc = NDT_OK;
+        } else {
+            rg.stereo = p->stereo;
+            rc = render_pass(ctx, rg, p->profile != 0, d_rgba, st, d_depth);
+        }
     }
     if (rc) return rc;
     if (stats) *stats = st;
     return NDT_OK;
 }
 
+extern "C" int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats)
+{
+    return ndt_hip_render_depth_device(ctx, p, d_rgba, nullptr, stats);
+}
+
 extern "C" int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, ndt_render_stats *stats)
+{
+    return ndt_hip_render_depth(ctx, p, rgba, nullptr, stats);
+}
+
+extern "C" int ndt_hip_render_depth(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, double *depth, ndt_render_stats *stats)
 {
     if (!ctx || !p || !rgba) return fail(NDT_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
-    const size_t bytes = (size_t)rows * (size_t)(p->width > 0 ? p->width : 0) * 4 * sizeof(double);
-    if (bytes == 0) return ndt_hip_render_device(ctx, p, (void *)rgba, stats);
+    const size_t img_bytes = (size_t)rows * (size_t)(p->width > 0 ? p->width : 0) * 4 * sizeof(double);
+    const size_t bytes = img_bytes + (depth ? img_bytes / 4 : 0);      // the depth map sits behind the image
+    if (img_bytes == 0) return ndt_hip_render_depth_device(ctx, p, (void *)rgba, nullptr, stats);
     if (ctx->d_out_bytes < bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_out) HIP_TRY(hipFree(ctx->d_out));
@@ -1650,9 +1726,11 @@ extern "C" int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, doub
         HIP_TRY(hipMalloc(&ctx->d_out, bytes));
         ctx->d_out_bytes = bytes;
     }
-    int rc = ndt_hip_render_device(ctx, p, ctx->d_out, stats);
+    void *d_depth = depth ? (void *)((char *)ctx->d_out + img_bytes) : nullptr;
+    int rc = ndt_hip_render_depth_device(ctx, p, ctx->d_out, d_depth, stats);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(rgba, ctx->d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(rgba, ctx->d_out, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (depth) HIP_TRY(hipMemcpyAsync(depth, d_depth, img_bytes / 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NDT_OK;
 }

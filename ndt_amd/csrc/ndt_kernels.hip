@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
     ws.sh_mask[g] = 0ull;
     double ip, jp;              // image position in pixels (ndt.c:590-592)
     bool live;
+    int eye = rg.eye;
     if (rg.samples) {
         live = g < rg.n_samples;
         ip = live ? rg.samples[2 * g] : 0.0;
@@ -100,28 +101,95 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
         ws.hit_obj[g] = -1;
         return;
     }
+    if (rg.stereo == 1) {           // SIDE_SIDE_3D, x_scale = 0.5 (ndt.c:591-601)
+        if (ip < rg.img_w / 2) { ip = ip / 0.5; eye = 0; }
+        else { ip = (ip - rg.img_w / 2) / 0.5; eye = 2; }
+    } else if (rg.stereo == 2) {    // OVER_UNDER_3D, y_scale = 0.5 (ndt.c:602-612)
+        if (jp < rg.img_h / 2) { jp = jp / 0.5; eye = 0; }
+        else { jp = (jp - rg.img_h / 2) / 0.5; eye = 2; }
+    }
     const double x = ip / (double)rg.img_w - 0.5;               // ndt.c:632
     const double y = -(jp / (double)rg.img_h - 0.5);            // ndt.c:633
-    double pos[N], orig[N], dx[N], dy[N], pixel[N], temp[N], look[N];
+    double pos[N], pixel[N], temp[N], look[N], cam[N];
     blob_vec<N>(blob, sd.off_cam, pos);
-    blob_vec<N>(blob, sd.off_cam + N, orig);
-    blob_vec<N>(blob, sd.off_cam + 2 * N, dx);
-    blob_vec<N>(blob, sd.off_cam + 3 * N, dy);
     const double focal = blob[sd.off_cam + 4 * N];
-    v_scale<N>(dx, rg.aspect_w / (double)rg.aspect_h, dx);      // ndt.c:926
-    v_copy<N>(pixel, orig);
-    v_scale<N>(dx, x, temp);
-    v_add<N>(pixel, temp, pixel);
-    v_scale<N>(dy, y, temp);
-    v_add<N>(pixel, temp, pixel);
-    const double screen_dist = v_dist<N>(orig, pos);
-    if (screen_dist > NDT_EPS) {
-        v_sub<N>(pixel, pos, temp);
-        v_scale<N>(temp, focal / screen_dist, temp);
-        v_add<N>(pos, temp, pixel);
+    const int ext = sd.off_cam + 4 * N + 8;                     // type, hFov, vFov, leftEye, rightEye, localX, localY, localZ
+    const int cam_type = (int)blob[ext];
+    if (cam_type != 0) {
+        // camera_target_point, camera.c:506-555: spherical (VR) / cylindrical (panorama) screen
+        const double azi = x * blob[ext + 1];
+        double view_x, view_y, view_z;
+        if (cam_type == 1) {
+            const double alt = y * blob[ext + 2];
+            view_x = focal * sin(azi) * cos(alt);
+            view_y = focal * sin(alt);
+            view_z = focal * cos(azi) * cos(alt);
+        } else {
+            const double y_size = 2.0 * tan(blob[ext + 2] / 2.0) * focal;
+            view_x = focal * sin(azi);
+            view_y = y * y_size;
+            view_z = focal * cos(azi);
+        }
+        double ax[N];
+        v_copy<N>(pixel, pos);
+        blob_vec<N>(blob, ext + 3 + 2 * N, ax);
+        v_scale<N>(ax, view_x, temp);
+        v_add<N>(pixel, temp, pixel);
+        blob_vec<N>(blob, ext + 3 + 3 * N, ax);
+        v_scale<N>(ax, view_y, temp);
+        v_add<N>(pixel, temp, pixel);
+        blob_vec<N>(blob, ext + 3 + 4 * N, ax);
+        v_scale<N>(ax, view_z, temp);
+        v_add<N>(pixel, temp, pixel);
+    } else {
+        double orig[N], dx[N], dy[N];
+        blob_vec<N>(blob, sd.off_cam + N, orig);
+        blob_vec<N>(blob, sd.off_cam + 2 * N, dx);
+        blob_vec<N>(blob, sd.off_cam + 3 * N, dy);
+        v_scale<N>(dx, rg.aspect_w / (double)rg.aspect_h, dx);  // ndt.c:926
+        v_copy<N>(pixel, orig);
+        v_scale<N>(dx, x, temp);
+        v_add<N>(pixel, temp, pixel);
+        v_scale<N>(dy, y, temp);
+        v_add<N>(pixel, temp, pixel);
+        const double screen_dist = v_dist<N>(orig, pos);
+        if (screen_dist > NDT_EPS) {
+            v_sub<N>(pixel, pos, temp);
+            v_scale<N>(temp, focal / screen_dist, temp);
+            v_add<N>(pos, temp, pixel);
+        }
     }
-    v_sub<N>(pixel, pos, look);
+    // the eye the ray starts from (ndt.c:491-502)
+    v_copy<N>(cam, pos);
+    if (eye == 0) blob_vec<N>(blob, ext + 3, cam);
+    else if (eye == 2) blob_vec<N>(blob, ext + 3 + N, cam);
+    if (cam_type != 0 && eye != 1) {
+        // VR: the eye goes round the centre with the view direction (ndt.c:519-525):
+        // vectNd_rotate2(virtCam, pos, localX, localZ, azi) = vectNd.c:271-325 with vectNd_orthogonalize (vectNd.c:35-57)
+        const double azi = x * blob[ext + 1];
+        double lx[N], lz[N], bx[N], bz[N], local[N], px[N], pz[N];
+        blob_vec<N>(blob, ext + 3 + 2 * N, lx);
+        blob_vec<N>(blob, ext + 3 + 4 * N, lz);
+        v_proj<N>(lx, lz, temp);
+        v_sub<N>(lx, temp, bx);
+        v_copy<N>(bz, lz);
+        v_unitize<N>(bx);
+        v_unitize<N>(bz);
+        v_sub<N>(cam, pos, local);
+        v_proj<N>(local, bx, px);
+        v_proj<N>(local, bz, pz);
+        const double vx = v_dot<N>(px, bx), vz = v_dot<N>(pz, bz);
+        double rx[N], rz[N];
+        v_scale<N>(bx, vx * cos(azi) - vz * sin(azi), rx);
+        v_scale<N>(bz, vz * cos(azi) + vx * sin(azi), rz);
+        v_sub<N>(cam, px, cam);
+        v_sub<N>(cam, pz, cam);
+        v_add<N>(cam, rx, cam);
+        v_add<N>(cam, rz, cam);
+    }
+    v_sub<N>(pixel, cam, look);
     v_unitize<N>(look);
+    v_copy<N>(pos, cam);
     store_soa<N>(ws.ray_o, ws.cap, g, pos);
     store_soa<N>(ws.ray_v, ws.cap, g, look);
     ws.frac[g] = 1.0;
@@ -459,6 +527,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             isect<N, true>(blob, sd, ws.hit_prim[g], src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
+            if (rg.want_depth && level == 0) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;    // ndt.c:366-370
             if (shaded) {
                 store_soa<N>(ws.hit_p, ws.cap, g, hit);
                 store_soa<N>(ws.hit_n, ws.cap, g, nrm);
@@ -466,6 +535,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
                 ws.hit_obj[g] = -1;
             }
         }
+        if (obj < 0 && rg.want_depth && level == 0) ws.depth[g] = 0.0;     // ndt.c:372-373
         if (!shaded) {
             // background (ndt.c:436-442); alpha is applied per pixel at the end
             ws.clr[0 * ws.cap + g] = blob[sd.off_cam + 4 * N + 4];

@@ -32,6 +32,7 @@ struct Workspace {
     int *sh_idx;                // [n_seg][cap] index of this node's shadow ray inside its light's segment
     unsigned long long *sh_mask;// [cap]      lights that fired a shadow ray
     int *count;                 // [cap]      trace_kd calls in this node's subtree
+    double *depth;              // [cap]      primaries of a depth-map render: 1/distance of the hit, 0 on a miss
     // shadow queue of the current bounce
     long long sh_cap;
     double *so, *sv;            // [N][sh_cap]
@@ -67,6 +68,9 @@ struct RenderGeom {
     int aspect_w, aspect_h;     // cam.dirX *= aspect_w/aspect_h            (ndt.c:926)
     const double *samples;      // list mode: (i, j) per sample, in pixels of the img_w x img_h image
     int n_samples;
+    int stereo;                 // ndt_stereo_mode: 1 side by side, 2 over/under split the image between the eyes (ndt.c:590-612)
+    int eye;                    // 0 left, 1 centre, 2 right: the eye when stereo does not split the image (anaglyph renders twice)
+    int want_depth;             // record 1/distance of the primary hits (depth maps, ndt.c:362-373)
 };
 
 // One k_trace launch = up to two parts, served from one work queue:

@@ -19,6 +19,7 @@ API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
     "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box",
+    "ndt_hip_render_depth_device", "ndt_hip_render_depth",
 ]
 
 
@@ -57,6 +58,8 @@ def load_library():
     lib.ndt_hip_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_depth_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_trace_rays.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
     lib.ndt_hip_quantize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.ndt_hip_synchronize.argtypes = [C.c_void_p]
@@ -117,17 +120,28 @@ class NdtHip:
         self._check(self.lib.ndt_hip_upload_scene(self.ctx, fs.byref()))
         self.scene = fs          # keep the arrays alive; also gives dims
 
-    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
+    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0):
         p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, profile)
+        p.stereo = int(stereo)      # ndt_stereo_mode: 0 mono, 1 side by side, 2 over/under, 3 anaglyph
         if aa is not None:
             # Whitted's recursive anti-aliasing, `-a diff,depth` (ndt.c:655-733)
             p.recursive_aa, p.aa_diff, p.aa_depth = 1, int(aa[0]), int(aa[1])
         return p
 
-    def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
+    def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0,
+               depth_map=False):
         """render_image for a row shard; returns ((rows, width, 4) float64 host array, RenderStats).
-        aa = (aa_diff, aa_depth) switches recursive anti-aliasing on."""
-        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa)
+        aa = (aa_diff, aa_depth) switches recursive anti-aliasing on; stereo = ndt_stereo_mode;
+        depth_map=True returns (rgba, (rows, width) depth map, stats)."""
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa, stereo)
+        if depth_map:
+            rows = shard_rows(height, row_begin, row_step)
+            out = np.zeros((rows, width, 4), dtype=np.float64)
+            dm = np.zeros((rows, width), dtype=np.float64)
+            st = RenderStats()
+            self._check(self.lib.ndt_hip_render_depth(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p),
+                                                      dm.ctypes.data_as(C.c_void_p), C.byref(st)))
+            return out, dm, st
         rows = shard_rows(height, row_begin, row_step)
         out = np.zeros((rows, width, 4), dtype=np.float64)
         st = RenderStats()

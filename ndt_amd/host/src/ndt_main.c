@@ -62,11 +62,12 @@ int main(int argc, char **argv)
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
     int depth = 128, threads = 1;
     int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
+    int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
                                         { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
     int ch;
-    while ((ch = getopt_long(argc, argv, "a:d:r:f:l:s:t:u:o:h", longopts, NULL)) != -1) {
+    while ((ch = getopt_long(argc, argv, "a:d:r:f:l:m:3:ps:t:u:o:zh", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
         switch (ch) {
         case 'a':       /* -a diff,depth (ndt.c:1453-1465); defaults 20,4 */
@@ -91,6 +92,18 @@ int main(int argc, char **argv)
             else if (n >= 1) { last = a1; }
             break;
         case 'l': depth = atoi(optarg); break;
+        case 'm':
+        case '3':       /* s(ide by side) / o(ver-under) / a(naglyph) / m(ono), ndt.c:1538-1572 */
+            switch (optarg[0]) {
+            case 'S': case 's': stereo = 1; printf("stereo = SIDE_SIDE_3D\n"); break;
+            case 'O': case 'o': stereo = 2; printf("stereo = OVER_UNDER_3D\n"); break;
+            case 'A': case 'a': stereo = 3; printf("stereo = ANAGLYPH_3D\n"); break;
+            case 'H': case 'h': fprintf(stderr, "HIDEF_3D is not implemented\n"); return 1;
+            default: stereo = 0; printf("stereo = MONO\n"); break;
+            }
+            break;
+        case 'p': specular = 0; printf("disabling specular highlights.\n"); break;
+        case 'z': want_depth = 1; printf("record_depth_map = yes\n"); break;
         case 's': scene_path = optarg; break;
         case 't': threads = atoi(optarg); break;
         case 'u': config = optarg; break;
@@ -99,7 +112,7 @@ int main(int argc, char **argv)
         case 1001: raw_path = optarg; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-a diff,depth] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+                            "          [-a diff,depth] [-m s|o|a|m] [-p] [-z] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -127,6 +140,7 @@ int main(int argc, char **argv)
     register_objects("objects");
 
     double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+    double *depth_map = NULL;
     for (int i = 0; i < frames && i <= last; ++i) {
         scene scn;
         setup(&scn, dims, i, frames, config);
@@ -145,7 +159,8 @@ int main(int argc, char **argv)
             continue;
         }
         double t0 = now_s();
-        if (!ndt_render_image_aa(&scn, width, height, threads, aa_diff, aa_depth, depth, rgba)) return 1;
+        if (want_depth && !depth_map) depth_map = (double *)malloc((size_t)width * height * sizeof(double));
+        if (!ndt_render_image_full(&scn, width, height, threads, aa_diff, aa_depth, stereo, specular, depth, rgba, depth_map)) return 1;
         printf("rendering took %.3fs\n", now_s() - t0);
         char dir[512], path[1024];
         mkdir("images", 0700);
@@ -155,6 +170,31 @@ int main(int argc, char **argv)
         snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn.name, width, height, i);
         write_ppm(path, rgba, width, height);
         printf("\tsaved %s\n", path);
+        if (depth_map) {
+            /* dbl_image_normalize (image.c:1025-1065) stretches the map to 0..1 before it is saved (ndt.c:1010-1016) */
+            double lo = depth_map[0], hi = depth_map[0];
+            for (long k = 0; k < (long)width * height; ++k) {
+                if (depth_map[k] < lo) lo = depth_map[k];
+                if (depth_map[k] > hi) hi = depth_map[k];
+            }
+            double *norm = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+            for (long k = 0; k < (long)width * height; ++k) {
+                const double v = hi > lo ? (depth_map[k] - lo) / (hi - lo) : 0.0;
+                norm[4 * k] = norm[4 * k + 1] = norm[4 * k + 2] = v;
+                norm[4 * k + 3] = 1.0;
+            }
+            mkdir("depth", 0700);
+            snprintf(path, sizeof(path), "depth/%s_%ix%i_%04i.ppm", scn.name, width, height, i);
+            write_ppm(path, norm, width, height);
+            printf("\tsaved %s\n", path);
+            free(norm);
+            if (raw_path) {
+                char dpath[1100];
+                snprintf(dpath, sizeof(dpath), "%s.depth", raw_path);
+                FILE *f = fopen(dpath, "wb");
+                if (f) { fwrite(depth_map, sizeof(double), (size_t)width * height, f); fclose(f); }
+            }
+        }
         if (raw_path) {
             FILE *f = fopen(raw_path, "wb");
             if (f) { fwrite(rgba, sizeof(double), (size_t)width * height * 4, f); fclose(f); }

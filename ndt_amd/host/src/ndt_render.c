@@ -13,6 +13,14 @@ int ndt_render_image(scene *scn, int width, int height, int threads, int max_opt
 int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int max_optic_depth,
                         double *rgba)
 {
+    return ndt_render_image_full(scn, width, height, threads, aa_diff, aa_depth, 0, 1, max_optic_depth, rgba, NULL);
+}
+
+/* everything render_image takes (ndt.c:900): stereo = the reference's stereo_mode (MONO .. ANAGLYPH_3D),
+ * specular = specular_enabled (`-p` clears it), depth = the depth map of `-z` (width*height doubles) or NULL */
+int ndt_render_image_full(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int stereo, int specular,
+                          int max_optic_depth, double *rgba, double *depth)
+{
     (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
     char err[256];
     ndt_flat_builder fb;
@@ -30,13 +38,14 @@ int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_d
         ndt_render_params p;
         memset(&p, 0, sizeof(p));
         p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = 1;
-        p.row_begin = 0; p.row_step = 1; p.specular = 1;
+        p.row_begin = 0; p.row_step = 1; p.specular = specular;
+        p.stereo = stereo;
         if (aa_depth >= 0 && aa_diff < 256) {       /* ndt.c:1040: otherwise the first pass is the image */
             p.recursive_aa = 1;
             p.aa_diff = aa_diff;
             p.aa_depth = aa_depth;
         }
-        if (ndt_hip_render(g_ctx, &p, rgba, NULL) == NDT_OK) ok = 1;
+        if (ndt_hip_render_depth(g_ctx, &p, rgba, depth, NULL) == NDT_OK) ok = 1;
         else fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
     }
     ndt_flat_builder_free(&fb);

@@ -177,6 +177,8 @@ typedef struct {
     int n_objs, n_items;
     const double *cam_pos, *cam_img_orig, *cam_dir_y;
     double cam_dir_x[ND];               /* scaled per render (ndt.c:926) */
+    /* the rest of the camera (ABI 2), NULL when the scene does not carry it */
+    const double *cam_left_eye, *cam_right_eye, *cam_local_x, *cam_local_y, *cam_local_z;
     const double *bb_lower, *bb_upper;
 } pscene;
 
@@ -334,6 +336,11 @@ static int prepare_scene(const ndt_flat_scene *fs, pscene *S)
     S->cam_img_orig = fs->vecs + fs->cam_img_orig_off;
     S->cam_dir_y = fs->vecs + fs->cam_dir_y_off;
     v_copy(S->cam_dir_x, fs->vecs + fs->cam_dir_x_off, S->n);
+    S->cam_left_eye = fs->cam_left_eye_off >= 0 ? fs->vecs + fs->cam_left_eye_off : NULL;
+    S->cam_right_eye = fs->cam_right_eye_off >= 0 ? fs->vecs + fs->cam_right_eye_off : NULL;
+    S->cam_local_x = fs->cam_local_x_off >= 0 ? fs->vecs + fs->cam_local_x_off : NULL;
+    S->cam_local_y = fs->cam_local_y_off >= 0 ? fs->vecs + fs->cam_local_y_off : NULL;
+    S->cam_local_z = fs->cam_local_z_off >= 0 ? fs->vecs + fs->cam_local_z_off : NULL;
     S->bb_lower = fs->vecs + fs->bb_lower_off;
     S->bb_upper = fs->vecs + fs->bb_upper_off;
     return NDT_OK;
@@ -1114,8 +1121,18 @@ static void apply_lights(tctx *T, int obj_idx, const double *src, const double *
 }
 
 /* get_ray_color, ndt.c:329-450.  `primary` only selects the counter. */
+static int get_ray_color_d(tctx *T, const double *src, const double *unit_look, pix *pixel, double pixel_frac,
+                           int max_depth, int primary, double *depth);
 static int get_ray_color(tctx *T, const double *src, const double *unit_look, pix *pixel, double pixel_frac,
                          int max_depth, int primary)
+{
+    return get_ray_color_d(T, src, unit_look, pixel, pixel_frac, max_depth, primary, NULL);
+}
+
+/* `depth` (primaries of a depth-map render only): 1/distance of the hit, 0 on a miss; left as it is
+ * when the hit lies within EPSILON of the ray origin (ndt.c:362-373) */
+static int get_ray_color_d(tctx *T, const double *src, const double *unit_look, pix *pixel, double pixel_frac,
+                           int max_depth, int primary, double *depth)
 {
     const pscene *S = T->S;
     const ndt_flat_scene *fs = S->fs;
@@ -1136,6 +1153,10 @@ static int get_ray_color(tctx *T, const double *src, const double *unit_look, pi
     if (primary) T->cnt.primary++; else T->cnt.secondary++;
     trace_kd(S, src, unit_look, hit, hit_normal, &obj_ptr, -1.0, T->mask);
     double trace_dist = v_dist(hit, src, n);   /* depth != NULL only for primaries; same value either way */
+    if (depth) {
+        if (trace_dist > EPS) *depth = 1.0 / trace_dist;
+        if (obj_ptr < 0) *depth = 0.0;
+    }
     if (obj_ptr >= 0 && trace_dist > EPS) {
         const pobj *obj = &S->objs[obj_ptr];
         apply_lights(T, obj_ptr, src, unit_look, hit, hit_normal, &clr);
@@ -1183,10 +1204,60 @@ static int get_ray_color(tctx *T, const double *src, const double *unit_look, pi
 }
 
 /* camera_target_point, CAMERA_NORMAL branch, camera.c:557-575 */
+/* vectNd_orthogonalize + vectNd_rotate2, vectNd.c:35-57, 271-325 */
+static void v_rotate2(const double *v, const double *center, const double *v1, const double *v2, double angle, double *res, int n)
+{
+    double basisX[ND], basisY[ND], temp[ND], localPos[ND], projX[ND], projY[ND], rotX[ND], rotY[ND];
+    v_proj(v1, v2, temp, n);
+    v_sub(v1, temp, basisX, n);
+    v_copy(basisY, v2, n);
+    v_unitize(basisX, n);
+    v_unitize(basisY, n);
+    v_sub(v, center, localPos, n);
+    v_proj(localPos, basisX, projX, n);
+    v_proj(localPos, basisY, projY, n);
+    double virtX = v_dot(projX, basisX, n);
+    double virtY = v_dot(projY, basisY, n);
+    v_scale(basisX, virtX * cos(angle) - virtY * sin(angle), rotX, n);
+    v_scale(basisY, virtY * cos(angle) + virtX * sin(angle), rotY, n);
+    double out[ND];
+    v_sub(v, projX, out, n);
+    v_sub(out, projY, out, n);
+    v_add(out, rotX, out, n);
+    v_add(out, rotY, out, n);
+    v_copy(res, out, n);
+}
+
+/* camera_target_point, camera.c:503-579: planar, spherical (VR) and cylindrical (panorama) screens */
 static void camera_target_point(const pscene *S, double x, double y, double dist, double *pixel)
 {
     int n = S->n;
     double temp[ND];
+    const int type = S->fs->cam_type;
+    if (type == 1 || type == 2) {
+        double view_x, view_y, view_z;
+        if (type == 1) {
+            double azi = x * S->fs->cam_h_fov;
+            double alt = y * S->fs->cam_v_fov;
+            view_x = dist * sin(azi) * cos(alt);
+            view_y = dist * sin(alt);
+            view_z = dist * cos(azi) * cos(alt);
+        } else {
+            double azi = x * S->fs->cam_h_fov;
+            double y_size = 2.0 * tan(S->fs->cam_v_fov / 2.0) * dist;
+            view_x = dist * sin(azi);
+            view_y = y * y_size;
+            view_z = dist * cos(azi);
+        }
+        v_copy(pixel, S->cam_pos, n);
+        v_scale(S->cam_local_x, view_x, temp, n);
+        v_add(pixel, temp, pixel, n);
+        v_scale(S->cam_local_y, view_y, temp, n);
+        v_add(pixel, temp, pixel, n);
+        v_scale(S->cam_local_z, view_z, temp, n);
+        v_add(pixel, temp, pixel, n);
+        return;
+    }
     v_copy(pixel, S->cam_img_orig, n);
     v_scale(S->cam_dir_x, x, temp, n);
     v_add(pixel, temp, pixel, n);
@@ -1205,7 +1276,17 @@ static void camera_target_point(const pscene *S, double x, double y, double dist
  * (SURVEY 8a row A3).  `literal` != 0 re-traces it like the reference does; otherwise the
  * sample is traced once and the loop's arithmetic is replayed on its colour -- identical
  * results, and `*k_out` (the repeat count) scales the ray counters. */
+enum { CAM_LEFT = 0, CAM_CENTER = 1, CAM_RIGHT = 2 };      /* camera_mode, ndt.c:452-454 */
+
+static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_optic_depth, int literal, int *k_out,
+                              int mode, double *depth);
 static void get_pixel_color(tctx *T, double x, double y, pix *clr, int max_optic_depth, int literal, int *k_out)
+{
+    get_pixel_color_m(T, x, y, clr, max_optic_depth, literal, k_out, CAM_CENTER, NULL);
+}
+
+static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_optic_depth, int literal, int *k_out,
+                              int mode, double *depth)
 {
     const pscene *S = T->S;
     int n = S->n;
@@ -1220,13 +1301,18 @@ static void get_pixel_color(tctx *T, double x, double y, pix *clr, int max_optic
     ray_counts before = T->cnt, one = { 0, 0, 0 };
     for (int i = 0; i < min_samples || (i < max_samples && clr_diff > max_diff); ++i) {
         if (i == 0 || literal) {
-            v_copy(virtCam, S->cam_pos, n);
+            v_copy(virtCam, mode == CAM_LEFT ? S->cam_left_eye : mode == CAM_RIGHT ? S->cam_right_eye : S->cam_pos, n);   /* ndt.c:491-502 */
             camera_target_point(S, x, y, S->fs->cam_focal_distance, pixel);
+            if ((S->fs->cam_type == 1 || S->fs->cam_type == 2) && mode != CAM_CENTER) {
+                /* VR: the eye goes round the centre with the view direction (ndt.c:519-525) */
+                double azi = x * S->fs->cam_h_fov;
+                v_rotate2(virtCam, S->cam_pos, S->cam_local_x, S->cam_local_z, azi, virtCam, n);
+            }
             v_sub(pixel, virtCam, look, n);
             l_clr.r = l_clr.g = l_clr.b = 0.0;
             l_clr.a = 1.0;
             v_unitize(look, n);
-            get_ray_color(T, virtCam, look, &l_clr, 1.0, max_optic_depth, 1);
+            get_ray_color_d(T, virtCam, look, &l_clr, 1.0, max_optic_depth, 1, depth);
             if (i == 0) {
                 one.primary = T->cnt.primary - before.primary;
                 one.secondary = T->cnt.secondary - before.secondary;
@@ -1270,20 +1356,52 @@ typedef struct {
     const int *row_of;      /* image row of every pass-1 row */
     int n1;
     long long resampled, aa_samples;
+    double *depth;          /* depth map (1/distance of the primary hit), or NULL */
 } job;
 
 /* render_pixel (ndt.c:578-653, MONO) + get_pixel_color: the sample at image position (i, j), both in
  * pixels of a width x height image (fractional for the anti-aliasing samples) */
-static void render_pixel(job *J, tctx *T, int width, int height, double i, double j, pix *clr)
+static void one_eye(job *J, tctx *T, double x, double y, pix *clr, int mode, double *depth)
 {
-    double x = i / (double)width - 0.5;
-    double y = -(j / (double)height - 0.5);
     int k = 0;
     ray_counts b = T->cnt;
-    get_pixel_color(T, x, y, clr, J->p->max_optic_depth, J->literal, &k);
+    get_pixel_color_m(T, x, y, clr, J->p->max_optic_depth, J->literal, &k, mode, depth);
     J->unique.primary += (T->cnt.primary - b.primary) / k;
     J->unique.secondary += (T->cnt.secondary - b.secondary) / k;
     J->unique.shadow += (T->cnt.shadow - b.shadow) / k;
+}
+
+static void render_pixel_d(job *J, tctx *T, int width, int height, double i, double j, pix *clr, double *depth)
+{
+    double ip = i, jp = j;
+    int mode = CAM_CENTER;
+    const int stereo = J->p->stereo;
+    if (stereo == NDT_STEREO_SIDE_SIDE) {           /* x_scale = 0.5, ndt.c:591-601, 913-914 */
+        if (i < width / 2) { ip = ip / 0.5; mode = CAM_LEFT; }
+        else { ip = (ip - width / 2) / 0.5; mode = CAM_RIGHT; }
+    }
+    if (stereo == NDT_STEREO_OVER_UNDER) {          /* y_scale = 0.5, ndt.c:602-612 */
+        if (j < height / 2) { jp = jp / 0.5; mode = CAM_LEFT; }
+        else { jp = (jp - height / 2) / 0.5; mode = CAM_RIGHT; }
+    }
+    double x = ip / (double)width - 0.5;
+    double y = -(jp / (double)height - 0.5);
+    if (stereo == NDT_STEREO_ANAGLYPH) {            /* ndt.c:636-647 */
+        pix left, right;
+        one_eye(J, T, x, y, &left, CAM_LEFT, depth);
+        one_eye(J, T, x, y, &right, CAM_RIGHT, NULL);
+        clr->r = 0.299 * left.r + 0.587 * left.g + 0.114 * left.b;
+        clr->g = 0;
+        clr->b = 0.299 * right.r + 0.587 * right.g + 0.114 * right.b;
+        clr->a = 1.0;
+    } else {
+        one_eye(J, T, x, y, clr, mode, depth);
+    }
+}
+
+static void render_pixel(job *J, tctx *T, int width, int height, double i, double j, pix *clr)
+{
+    render_pixel_d(J, T, width, height, i, j, clr, NULL);
 }
 
 static void tctx_open(tctx *T, job *J)
@@ -1306,11 +1424,13 @@ static void *render_rows(void *arg)
     for (int j = p->row_begin; j < height; j += p->row_step, ++local) {
         if (local % J->threads != J->thr)
             continue;
+        double depth = 0.0;     /* render_line's variable (ndt.c:739) is not initialised; 0 here */
         for (int i = 0; i < width; ++i) {
             pix clr;
-            render_pixel(J, &T, width, height, i, j, &clr);
+            render_pixel_d(J, &T, width, height, i, j, &clr, J->depth ? &depth : NULL);
             double *out = J->rgba + ((size_t)local * width + i) * 4;    /* dbl_image_set_pixel, image.c:126 */
             out[0] = clr.r; out[1] = clr.g; out[2] = clr.b; out[3] = clr.a;
+            if (J->depth) J->depth[(size_t)local * width + i] = depth;   /* ndt.c:753-756 */
         }
     }
     J->cnt = T.cnt;
@@ -1432,7 +1552,9 @@ static void *resample_rows(void *arg)
 
 static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
 {
-    if (fs->cam_type != 0) return NDT_E_UNSUPPORTED;
+    if (fs->cam_type < 0 || fs->cam_type > 2) return NDT_E_UNSUPPORTED;
+    if (fs->cam_type != 0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0 || fs->cam_local_z_off < 0)) return NDT_E_INVALID;
+    if (p && p->stereo != NDT_STEREO_MONO && (fs->cam_left_eye_off < 0 || fs->cam_right_eye_off < 0)) return NDT_E_INVALID;
     for (int i = 0; i < fs->n_lights; ++i) {
         const ndt_flat_light *L = &fs->lights[i];
         if (L->type == NDT_LIGHT_DISK || L->type == NDT_LIGHT_RECT)
@@ -1442,7 +1564,8 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     }
     if (p && (p->samples != 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
         return NDT_E_INVALID;
-    if (p && p->stereo != 0) return NDT_E_UNSUPPORTED;
+    if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)) return NDT_E_UNSUPPORTED;
+    if (p && p->stereo != NDT_STEREO_MONO && p->recursive_aa) return NDT_E_UNSUPPORTED;
     /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
     if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0) return NDT_E_UNSUPPORTED;
     return NDT_OK;
@@ -1463,8 +1586,18 @@ static void run_jobs(job *jobs, int threads, void *(*fn)(void *))
 /* render_image, ndt.c:900.  flags bit0: literal re-sampling (trace all k samples like the
  * reference; only changes run time and nothing else).  stats->rays_* = unique rays,
  * stats->rays_ref_equiv = what the reference's trace_kd counter reads. */
+int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p, double *rgba, double *depth,
+                            ndt_render_stats *stats, int threads, int flags);
 int ndt_oracle_render(const ndt_flat_scene *fs, const ndt_render_params *p, double *rgba, ndt_render_stats *stats,
                       int threads, int flags)
+{
+    return ndt_oracle_render_depth(fs, p, rgba, NULL, stats, threads, flags);
+}
+
+/* the same with the depth map render_image fills when it is given a depth file name (ndt.c:930-935, 753-756):
+ * rows x width doubles, 1/distance of the primary hit, 0 where the primary ray misses */
+int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p, double *rgba, double *depth,
+                            ndt_render_stats *stats, int threads, int flags)
 {
     pscene S;
     int rc = check_supported(fs, p);
@@ -1479,10 +1612,16 @@ int ndt_oracle_render(const ndt_flat_scene *fs, const ndt_render_params *p, doub
     for (int i = 0; i < threads; ++i) {
         jobs[i].S = &S; jobs[i].p = p; jobs[i].rgba = rgba; jobs[i].thr = i; jobs[i].threads = threads;
         jobs[i].literal = flags & 1;
+        jobs[i].depth = depth;
     }
     ray_counts cnt1 = { 0, 0, 0 };
     double *pass1 = NULL;
     int *row_of = NULL;
+    if (depth && p->recursive_aa) {
+        free(jobs);
+        free_scene(&S);
+        return NDT_E_UNSUPPORTED;
+    }
     if (!p->recursive_aa) {
         run_jobs(jobs, threads, render_rows);
     } else {

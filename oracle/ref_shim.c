@@ -171,12 +171,14 @@ static void dump_node(FILE *f, kd_node_t *n, int me)
     }
 }
 
+static int scene_v2 = 0;     /* --scene-v2: also write the camera2 block (aperture, fields of view, eyes, local axes) */
+
 static void dump_scene(const char *path, scene *scn)
 {
     int dims = scn->dimensions;
     FILE *f = fopen(path, "w");
     if (!f) { perror(path); exit(2); }
-    fprintf(f, "ndtscene 1\n");
+    fprintf(f, "ndtscene %d\n", scene_v2 ? 2 : 1);
     fprintf(f, "name %s\n", scn->name);
     fprintf(f, "dims %d\n", dims);
     fprintf(f, "camera type %d focal_distance %a\n", (int)scn->cam.type, scn->cam.focal_distance);
@@ -184,6 +186,14 @@ static void dump_scene(const char *path, scene *scn)
     put_vec(f, "cam_img_orig", &scn->cam.imgOrig, dims);
     put_vec(f, "cam_dir_x", &scn->cam.dirX, dims);
     put_vec(f, "cam_dir_y", &scn->cam.dirY, dims);
+    if (scene_v2) {
+        fprintf(f, "camera2 aperture %a hfov %a vfov %a\n", scn->cam.aperture_radius, scn->cam.hFov, scn->cam.vFov);
+        put_vec(f, "cam_left_eye", &scn->cam.leftEye, dims);
+        put_vec(f, "cam_right_eye", &scn->cam.rightEye, dims);
+        put_vec(f, "cam_local_x", &scn->cam.localX, dims);
+        put_vec(f, "cam_local_y", &scn->cam.localY, dims);
+        put_vec(f, "cam_local_z", &scn->cam.localZ, dims);
+    }
     fprintf(f, "ambient %a %a %a\n", scn->ambient.red, scn->ambient.green, scn->ambient.blue);
     fprintf(f, "background %a %a %a %a\n", scn->bg_red, scn->bg_green, scn->bg_blue, scn->bg_alpha);
     fprintf(f, "lights %d\n", scn->num_lights);
@@ -275,10 +285,14 @@ int main(int argc, char **argv)
     int no_render = arg_flag(argc, argv, "--no-render");
     const char *aa = arg_str(argc, argv, "--aa", NULL);
     const char *yaml_out = arg_str(argc, argv, "--yaml-out", NULL);
+    int stereo = atoi(arg_str(argc, argv, "--stereo", "0"));     /* stereo_mode, ndt.c:46-48 */
+    const char *depth_out = arg_str(argc, argv, "--depth-out", NULL);
+    scene_v2 = arg_flag(argc, argv, "--scene-v2");
     if (!objdir || !scene_so || width < 1 || height < 1) {
         fprintf(stderr, "usage: ndt_ref_shim --objects DIR --scene X.so --dims N [--frame F] [--config S] --res WxH\n"
                         "       [--threads T] [--depth L] [--scene-out F] [--fb-out F] [--rays-in F --rays-out F]\n"
-                        "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH] [--yaml-out F]\n");
+                        "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH] [--yaml-out F]\n"
+                        "       [--stereo MODE] [--depth-out F] [--scene-v2]\n");
         return 2;
     }
 
@@ -399,11 +413,26 @@ int main(int argc, char **argv)
         n_trace_closest = n_trace_shadow = 0;
         counting = 1;
         double t0 = now_s();
-        render_image(&scn, name, NULL, width, height, 1, 0 /* MONO */, threads, 20, 4, max_depth, &img, NULL);
+        char dname[4096];
+        snprintf(dname, sizeof(dname), "%s/ndt_ref_shim_depth_%d.jpg", tmpdir, (int)getpid());
+        image_t dimg;
+        dbl_image_init(&dimg);
+        render_image(&scn, name, depth_out ? dname : NULL, width, height, 1, stereo, threads, 20, 4, max_depth, &img,
+                     depth_out ? &dimg : NULL);
         double t1 = now_s();
         counting = 0;
         while (image_active_saves() > 0) usleep(1000);   /* background save thread (image.c:750) */
         unlink(name);
+        if (depth_out) {
+            /* the depth map render_line filled (ndt.c:753-756): r = g = b = 1/distance of the primary hit */
+            unlink(dname);
+            FILE *f = fopen(depth_out, "wb");
+            if (!f) { perror(depth_out); return 2; }
+            for (long i = 0; i < (long)width * height; ++i)
+                fwrite((double *)dimg.pixels + 4 * i, sizeof(double), 1, f);
+            fclose(f);
+            image_free(&dimg);
+        }
         printf("ref_shim: render_s %.6f threads %d width %d height %d\n", t1 - t0, threads, width, height);
         printf("ref_shim: rays_closest %lld rays_shadow %lld rays_total %lld\n", n_trace_closest, n_trace_shadow,
                n_trace_closest + n_trace_shadow);

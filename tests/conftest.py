@@ -28,22 +28,28 @@ class Oracle:
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True)
         self.lib = C.CDLL(path)
         self.lib.ndt_oracle_render.restype = C.c_int
+        self.lib.ndt_oracle_render_depth.restype = C.c_int
         self.lib.ndt_oracle_trace_rays.restype = C.c_int
 
-    def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1, aa=None):
-        """aa = (aa_diff, aa_depth) switches Whitted's recursive anti-aliasing on (-a diff,depth)."""
+    def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1, aa=None,
+               stereo=0, depth_map=False):
+        """aa = (aa_diff, aa_depth) switches Whitted's recursive anti-aliasing on (-a diff,depth);
+        stereo = ndt_stereo_mode; depth_map=True also returns the 1/distance map: (rgba, depth, stats)."""
         from ndt_amd import shard_rows
         rows = shard_rows(height, row_begin, row_step)
         p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, 0)
         if aa is not None:
             p.recursive_aa, p.aa_diff, p.aa_depth = 1, aa[0], aa[1]
+        p.stereo = stereo
         st = RenderStats()
         out = np.zeros((rows, width, 4), dtype=np.float64)
+        dm = np.zeros((rows, width), dtype=np.float64) if depth_map else None
         threads = threads or min(8, os.cpu_count() or 1)
-        rc = self.lib.ndt_oracle_render(fs.byref(), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st),
-                                        C.c_int(threads), C.c_int(1 if literal else 0))
+        rc = self.lib.ndt_oracle_render_depth(fs.byref(), C.byref(p), out.ctypes.data_as(C.c_void_p),
+                                              dm.ctypes.data_as(C.c_void_p) if depth_map else None, C.byref(st),
+                                              C.c_int(threads), C.c_int(1 if literal else 0))
         assert rc == 0, "oracle render failed rc=%d" % rc
-        return out, st
+        return (out, dm, st) if depth_map else (out, st)
 
     def trace(self, fs, rays):
         d = fs.dims
@@ -100,3 +106,5 @@ KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c
              "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d"]
 FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]
+# stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
+VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

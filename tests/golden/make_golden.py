@@ -70,6 +70,18 @@ CASES = {
                               share_scene="c1_hypercube3d"),
     "aa_zoo4d": dict(scene="parity_zoo", dims=4, res=(48, 27), depth=6, fb=True, kat=0, aa=(8, 3),
                      share_scene="zoo4d"),
+    # stereo modes (-m, ndt.c:46-48, 590-650), depth maps (-z, ndt.c:362-373, 753-756), VR / panorama cameras
+    # (camera.c:506-555): scenes in `ndtscene 2` (eyes, local axes, fields of view)
+    "st_zoo4d_sbs": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, stereo=1, v2=True),
+    "st_zoo4d_ou": dict(scene="parity_zoo", dims=4, res=(48, 54), depth=6, fb=True, kat=0, stereo=2, v2=True,
+                        share_scene="st_zoo4d_sbs"),
+    "st_zoo3d_anaglyph": dict(scene="parity_zoo", dims=3, res=(48, 36), depth=6, fb=True, kat=0, stereo=3, v2=True,
+                              depth_map=True),
+    "vr_zoo4d": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, v2=True, config="vr",
+                     depth_map=True),
+    "pano_zoo5d_sbs": dict(scene="parity_zoo", dims=5, res=(64, 32), depth=5, fb=True, kat=0, v2=True, config="pano",
+                           stereo=1),
+    "depth_c3_random4d": dict(scene="random", dims=4, res=(64, 36), depth=4, fb=True, kat=0, v2=True, depth_map=True),
 }
 
 
@@ -148,7 +160,7 @@ def generate(name, case):
     with tempfile.TemporaryDirectory() as tmp:
         scene_txt = os.path.join(tmp, "scene.txt")
         # pass 1: scene only
-        run_shim(base + ["--tmp", tmp, "--scene-out", scene_txt, "--no-render"])
+        run_shim(base + ["--tmp", tmp, "--scene-out", scene_txt, "--no-render"] + (["--scene-v2"] if case.get("v2") else []))
         fs = load_scene(scene_txt)
         share = case.get("share_scene")
         if share:
@@ -168,6 +180,11 @@ def generate(name, case):
         args = base + ["--tmp", tmp, "--fb-out", os.path.join(tmp, "fb.bin")]
         if case.get("aa"):
             args += ["--aa", "%d,%d" % case["aa"]]
+        if case.get("stereo"):
+            args += ["--stereo", str(case["stereo"])]
+            meta["stereo"] = case["stereo"]
+        if case.get("depth_map"):
+            args += ["--depth-out", os.path.join(tmp, "depth.bin")]
         if case["kat"]:
             rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"])
             rays.tofile(os.path.join(tmp, "rays.bin"))
@@ -176,6 +193,8 @@ def generate(name, case):
         fb = np.fromfile(os.path.join(tmp, "fb.bin")).reshape(h, w, 4)
         if case.get("fb"):
             arrays["fb"] = fb
+        if case.get("depth_map"):
+            arrays["depth"] = np.fromfile(os.path.join(tmp, "depth.bin")).reshape(h, w)
         if case.get("rgba8"):
             # pixel_d2c (image.h:36-39): the byte the reference's PNG/JPEG writer stores
             arrays["rgba8"] = (np.sqrt(np.maximum(0.0, np.minimum(1.0, fb))) * 255).astype(np.uint8)

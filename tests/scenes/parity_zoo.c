@@ -58,6 +58,17 @@ int scene_setup(scene *scn, int dims, int frame, int frames, char *config)
     vectNd_reset(&d);
     vectNd_set(&d, 1, 1.0);
     camera_set_aim(&scn->cam, &p, &q, &d, 0.1 * frame);
+    /* config "vr" / "pano": spherical / cylindrical screen (camera.c:506-555) with fields of view that
+     * keep the whole zoo in the picture */
+    if (config && strstr(config, "vr")) {
+        scn->cam.type = CAMERA_VR;
+        scn->cam.hFov = 1.9;
+        scn->cam.vFov = 1.1;
+    } else if (config && strstr(config, "pano")) {
+        scn->cam.type = CAMERA_PANO;
+        scn->cam.hFov = 2.3;
+        scn->cam.vFov = 0.9;
+    }
 
     /* lights: ambient entry, point, spot (cone cuts through the scene), directional */
     light *l = NULL;

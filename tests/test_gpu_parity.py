@@ -9,7 +9,7 @@ may differ in the last ulps, hence TOL_TIGHT is what we actually expect and TOL_
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -188,3 +188,38 @@ def test_antialiasing_cutoffs(gpu, oracle):
         out, st = gpu.render(g.width, g.height, g.depth, aa=aa)
         assert np.abs(out - want).max() < TOL_TIGHT
         assert st.pixels_resampled == so.pixels_resampled
+
+
+@pytest.mark.parametrize("name", VIEW_CASES)
+def test_stereo_vr_pano_and_depth_maps_vs_reference(gpu, name):
+    """Stereo modes, VR / panorama cameras (sin/cos/tan from ocml instead of glibc: last-ulp
+    differences in the primary rays) and depth maps against the compiled reference."""
+    g = golden(name)
+    stereo = g.meta.get("stereo", 0)
+    gpu.upload_scene(g.scene)
+    if "depth" in g.data:
+        out, dm, st = gpu.render(g.width, g.height, g.depth, stereo=stereo, depth_map=True)
+        assert np.abs(dm - g.data["depth"]).max() < TOL_TIGHT
+    else:
+        out, st = gpu.render(g.width, g.height, g.depth, stereo=stereo)
+    diff = np.abs(out - g.data["fb"])
+    assert diff.max() < (TOL_TIGHT if g.scene.cam_type == 0 else 1e-7), "max abs diff %g" % diff.max()
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+def test_stereo_row_shards(gpu):
+    g = golden("st_zoo4d_ou")
+    gpu.upload_scene(g.scene)
+    full, _ = gpu.render(g.width, g.height, g.depth, stereo=2)
+    for begin in range(2):
+        part, dm, _ = gpu.render(g.width, g.height, g.depth, row_begin=begin, row_step=2, stereo=2, depth_map=True)
+        assert np.array_equal(part, full[begin::2])
+        assert dm.shape == part.shape[:2]
+
+
+def test_stereo_needs_the_eyes(gpu):
+    from ndt_amd.hip import NdtHipError
+    g = golden("c1_hypercube3d")            # an `ndtscene 1` file: no eyes
+    gpu.upload_scene(g.scene)
+    with pytest.raises(NdtHipError):
+        gpu.render(32, 32, 4, stereo=1)

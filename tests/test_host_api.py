@@ -38,7 +38,13 @@ CASES = {
     "zoo3d_mirror": ("parity_zoo", 3, 0, "mirror"),
     "zoo5d_f2": ("parity_zoo", 5, 2, None),
     "zoo6d": ("parity_zoo", 6, 0, None),
+    # `ndtscene 2` fixtures: the camera2 block (eyes, local axes, fields of view) must match too
+    "st_zoo4d_sbs": ("parity_zoo", 4, 0, None),
+    "st_zoo3d_anaglyph": ("parity_zoo", 3, 0, None),
+    "vr_zoo4d": ("parity_zoo", 4, 0, "vr"),
+    "pano_zoo5d_sbs": ("parity_zoo", 5, 0, "pano"),
 }
+V2 = {"st_zoo4d_sbs", "st_zoo3d_anaglyph", "vr_zoo4d", "pano_zoo5d_sbs"}
 OWN_SRC = os.path.join(ROOT, "tests", "scenes")
 
 
@@ -60,11 +66,14 @@ def _fixture_text(name):
         return f.read()
 
 
-def _dump(driver, scene_so, dims, frame, out, config=None):
+def _dump(driver, scene_so, dims, frame, out, config=None, v2=False):
     cmd = [driver, "-s", scene_so, "-d", str(dims), "-f", "%d:%d" % (frame, frame), "--dump-scene", out]
     if config:
         cmd += ["-u", config]
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(out))
+    env = dict(os.environ)
+    if v2:
+        env["NDT_NDTSCENE_V2"] = "1"       # plain pinhole scenes are written as version 1 unless asked
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(out), env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     with open(out) as f:
         return f.read()
@@ -84,7 +93,7 @@ def test_reference_scene_sources_compile_unchanged_and_flatten_identically(drive
     r = subprocess.run(["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-fPIC", "-shared", "-Wall", "-o", so,
                         str(tmp_path / "scenes" / (prog + ".c"))], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config) == _fixture_text(name)
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config, name in V2) == _fixture_text(name)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built (make -C oracle ref)")
@@ -92,7 +101,7 @@ def test_reference_scene_sources_compile_unchanged_and_flatten_identically(drive
 def test_reference_built_scene_binaries_load_unchanged(driver, tmp_path, name):
     prog, dims, frame, config = CASES[name]
     so = os.path.join(REF_BIN, prog + ".so")
-    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config) == _fixture_text(name)
+    assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config, name in V2) == _fixture_text(name)
 
 
 @pytest.mark.gpu
@@ -114,3 +123,26 @@ def test_end_to_end_reference_scene_to_pixels(driver, tmp_path, name):
     assert np.abs(fb - g.data["fb"]).max() < 1e-9
     ppm = [p for p in (tmp_path / "images").rglob("*.ppm")]
     assert len(ppm) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,flags", [("st_zoo4d_sbs", ["-m", "s"]), ("st_zoo3d_anaglyph", ["-m", "a", "-z"]),
+                                        ("vr_zoo4d", ["-z"])])
+def test_driver_stereo_and_depth_flags(driver, tmp_path, name, flags):
+    """`ndt_hip -m s|o|a` and `-z` (ndt.c:1533-1573, 1726-1729) end to end against the reference's pixels."""
+    prog, dims, frame, config = CASES[name]
+    g = golden(name)
+    raw = str(tmp_path / "fb.f64")
+    cmd = [driver, "-s", os.path.join(REF_BIN, prog + ".so"), "-d", str(dims), "-f", "0", "-r", "%dx%d" % (g.width, g.height),
+           "-l", str(g.depth), "--raw", raw] + flags
+    if config:
+        cmd += ["-u", config]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    fb = np.fromfile(raw).reshape(g.height, g.width, 4)
+    assert np.abs(fb - g.data["fb"]).max() < 1e-7
+    if "-z" in flags:
+        dm = np.fromfile(raw + ".depth").reshape(g.height, g.width)
+        assert np.abs(dm - g.data["depth"]).max() < 1e-9
+        assert len(list((tmp_path / "depth").glob("*.ppm"))) == 1

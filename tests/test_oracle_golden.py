@@ -7,7 +7,7 @@ same glibc libm, no FMA, SSE lane-pair dot order.
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -88,3 +88,21 @@ def test_recursive_antialiasing_row_shards(oracle):
     for begin in range(3):
         part, _ = oracle.render(g.scene, g.width, g.height, g.depth, row_begin=begin, row_step=3, aa=aa)
         assert np.array_equal(part, full[begin::3])
+
+
+@pytest.mark.parametrize("name", VIEW_CASES)
+def test_stereo_vr_pano_and_depth_maps(oracle, name):
+    """Stereo modes (ndt.c:590-650), VR / panorama screens with the eyes going round the centre
+    (camera.c:506-555, ndt.c:519-525) and depth maps (ndt.c:362-373): framebuffer, depth map and
+    trace_kd count of the compiled reference.  The spherical / cylindrical screens go through
+    sin/cos/tan of the same glibc, so even those are bit-exact here."""
+    g = golden(name)
+    stereo = g.meta.get("stereo", 0)
+    if "depth" in g.data:
+        out, dm, st = oracle.render(g.scene, g.width, g.height, g.depth, stereo=stereo, depth_map=True)
+        assert np.array_equal(dm, g.data["depth"])
+        assert (dm > 0).any()
+    else:
+        out, st = oracle.render(g.scene, g.width, g.height, g.depth, stereo=stereo)
+    assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
+    assert st.rays_ref_equiv == g.meta["rays_total"]
