@@ -7,6 +7,7 @@
  * scene of the last frame as an ndtscene file instead of rendering. */
 #include <dlfcn.h>
 #include <getopt.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 
@@ -38,6 +39,115 @@ static int write_ppm(const char *path, const double *rgba, int w, int h)
     return 0;
 }
 
+
+/* ---- one frame: flatten, upload, render, save (what follows scene_setup in the reference's frame loop) */
+static struct {
+    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth;
+    const char *raw_path;
+} job_opts;
+
+static int render_frame(scene *scn, int i)
+{
+    const int width = job_opts.width, height = job_opts.height;
+    double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+    double *depth_map = job_opts.want_depth ? (double *)malloc((size_t)width * height * sizeof(double)) : NULL;
+    double t0 = now_s();
+    if (!ndt_render_image_full(scn, width, height, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth, job_opts.stereo,
+                               job_opts.specular, job_opts.depth, rgba, depth_map)) {
+        free(rgba);
+        free(depth_map);
+        return 0;
+    }
+    printf("rendering took %.3fs\n", now_s() - t0);
+    char dir[512], path[1024];
+    mkdir("images", 0700);
+    snprintf(dir, sizeof(dir), "images/%s", scn->name); mkdir(dir, 0700);
+    snprintf(dir, sizeof(dir), "images/%s/%id", scn->name, job_opts.dims); mkdir(dir, 0700);
+    snprintf(dir, sizeof(dir), "images/%s/%id/%ix%i", scn->name, job_opts.dims, width, height); mkdir(dir, 0700);
+    snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn->name, width, height, i);
+    write_ppm(path, rgba, width, height);
+    printf("\tsaved %s\n", path);
+    if (depth_map) {
+        /* dbl_image_normalize (image.c:1025-1065) stretches the map to 0..1 before it is saved (ndt.c:1010-1016) */
+        double lo = depth_map[0], hi = depth_map[0];
+        for (long k = 0; k < (long)width * height; ++k) {
+            if (depth_map[k] < lo) lo = depth_map[k];
+            if (depth_map[k] > hi) hi = depth_map[k];
+        }
+        double *norm = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+        for (long k = 0; k < (long)width * height; ++k) {
+            const double v = hi > lo ? (depth_map[k] - lo) / (hi - lo) : 0.0;
+            norm[4 * k] = norm[4 * k + 1] = norm[4 * k + 2] = v;
+            norm[4 * k + 3] = 1.0;
+        }
+        mkdir("depth", 0700);
+        snprintf(path, sizeof(path), "depth/%s_%ix%i_%04i.ppm", scn->name, width, height, i);
+        write_ppm(path, norm, width, height);
+        printf("\tsaved %s\n", path);
+        free(norm);
+        if (job_opts.raw_path) {
+            char dpath[1100];
+            snprintf(dpath, sizeof(dpath), "%s.depth", job_opts.raw_path);
+            FILE *f = fopen(dpath, "wb");
+            if (f) { fwrite(depth_map, sizeof(double), (size_t)width * height, f); fclose(f); }
+        }
+    }
+    if (job_opts.raw_path) {
+        FILE *f = fopen(job_opts.raw_path, "wb");
+        if (f) { fwrite(rgba, sizeof(double), (size_t)width * height * 4, f); fclose(f); }
+    }
+    free(rgba);
+    free(depth_map);
+    return 1;
+}
+
+/* ---- bounded queue of frames between the scene program (producer) and the render workers */
+typedef struct { scene *scn; int frame; } frame_job;
+static frame_job *queue = NULL;
+static int queue_cap = 0, queue_n = 0, queue_head = 0, queue_done = 0, worker_failed = 0;
+static pthread_mutex_t queue_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t queue_not_full = PTHREAD_COND_INITIALIZER, queue_not_empty = PTHREAD_COND_INITIALIZER;
+
+static void queue_push(scene *scn, int frame)
+{
+    pthread_mutex_lock(&queue_mu);
+    while (queue_n == queue_cap) pthread_cond_wait(&queue_not_full, &queue_mu);
+    queue[(queue_head + queue_n) % queue_cap].scn = scn;
+    queue[(queue_head + queue_n) % queue_cap].frame = frame;
+    ++queue_n;
+    pthread_cond_signal(&queue_not_empty);
+    pthread_mutex_unlock(&queue_mu);
+}
+
+static void queue_close(void)
+{
+    pthread_mutex_lock(&queue_mu);
+    queue_done = 1;
+    pthread_cond_broadcast(&queue_not_empty);
+    pthread_mutex_unlock(&queue_mu);
+}
+
+static void *worker_main(void *arg)
+{
+    (void)arg;
+    for (;;) {
+        pthread_mutex_lock(&queue_mu);
+        while (queue_n == 0 && !queue_done) pthread_cond_wait(&queue_not_empty, &queue_mu);
+        if (queue_n == 0) {
+            pthread_mutex_unlock(&queue_mu);
+            return NULL;
+        }
+        frame_job j = queue[queue_head];
+        queue_head = (queue_head + 1) % queue_cap;
+        --queue_n;
+        pthread_cond_signal(&queue_not_full);
+        pthread_mutex_unlock(&queue_mu);
+        if (!render_frame(j.scn, j.frame)) worker_failed = 1;
+        scene_free(j.scn);
+        free(j.scn);
+    }
+}
+
 /* scenes/yaml.c:14-50 */
 static int yaml_scene_frames(int dimensions, char *config)
 {
@@ -62,12 +172,13 @@ int main(int argc, char **argv)
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
     int depth = 128, threads = 1;
     int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
+    int jobs = 1;           /* -j: frames in flight */
     int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
                                         { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
     int ch;
-    while ((ch = getopt_long(argc, argv, "a:d:r:f:l:m:3:ps:t:u:o:zh", longopts, NULL)) != -1) {
+    while ((ch = getopt_long(argc, argv, "a:d:r:f:j:l:m:3:ps:t:u:o:zh", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
         switch (ch) {
         case 'a':       /* -a diff,depth (ndt.c:1453-1465); defaults 20,4 */
@@ -91,6 +202,7 @@ int main(int argc, char **argv)
             else if (n >= 2) { first = a1; last = a2; }
             else if (n >= 1) { last = a1; }
             break;
+        case 'j': jobs = atoi(optarg); break;
         case 'l': depth = atoi(optarg); break;
         case 'm':
         case '3':       /* s(ide by side) / o(ver-under) / a(naglyph) / m(ono), ndt.c:1538-1572 */
@@ -112,7 +224,7 @@ int main(int argc, char **argv)
         case 1001: raw_path = optarg; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-a diff,depth] [-m s|o|a|m] [-p] [-z] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+                            "          [-a diff,depth] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -139,69 +251,58 @@ int main(int argc, char **argv)
     if (last < 0) last = frames - 1;
     register_objects("objects");
 
-    double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
-    double *depth_map = NULL;
+    job_opts.dims = dims; job_opts.width = width; job_opts.height = height; job_opts.depth = depth; job_opts.threads = threads;
+    job_opts.aa_diff = aa_diff; job_opts.aa_depth = aa_depth; job_opts.stereo = stereo; job_opts.specular = specular;
+    job_opts.want_depth = want_depth; job_opts.raw_path = raw_path;
+    /* -j K: K frames in flight.  The scene program runs on this thread, frame after frame (it may
+     * keep state between frames, ndt.c:1818-1825); everything after it -- bounding spheres, kd-tree,
+     * upload, render, image files -- happens on K worker threads, each with its own GPU context.
+     * This is the reference's MPI_MODE_FRAME (rank 0 builds the scenes, the others render, ndt.c:1770-1830)
+     * inside one process. */
+    pthread_t *workers = NULL;
+    if (jobs > 1 && !dump_path) {
+        workers = (pthread_t *)calloc((size_t)jobs, sizeof(pthread_t));
+        queue_cap = jobs;
+        queue = (frame_job *)calloc((size_t)queue_cap, sizeof(frame_job));
+        for (int k = 0; k < jobs; ++k) pthread_create(&workers[k], NULL, worker_main, NULL);
+    }
+    double t_all = now_s();
+    int rendered = 0;
     for (int i = 0; i < frames && i <= last; ++i) {
-        scene scn;
-        setup(&scn, dims, i, frames, config);
+        scene *scn = (scene *)calloc(1, sizeof(scene));
+        setup(scn, dims, i, frames, config);
         if (i < first) {            /* earlier frames still run scene_setup (ndt.c:1818-1825) */
-            scene_free(&scn);
+            scene_free(scn);
+            free(scn);
             continue;
         }
-        printf("Scene has %i objects and %i lights\n", scn.num_objects, scn.num_lights);
+        printf("Scene has %i objects and %i lights\n", scn->num_objects, scn->num_lights);
         if (dump_path) {
             char err[256];
             ndt_flat_builder fb;
-            if (ndt_flatten_scene(&scn, &fb, err, sizeof(err)) != 0) { fprintf(stderr, "%s\n", err); return 1; }
-            if (i == last || i == frames - 1) ndt_write_ndtscene(&fb.fs, scn.name, dump_path);
+            if (ndt_flatten_scene(scn, &fb, err, sizeof(err)) != 0) { fprintf(stderr, "%s\n", err); return 1; }
+            if (i == last || i == frames - 1) ndt_write_ndtscene(&fb.fs, scn->name, dump_path);
             ndt_flat_builder_free(&fb);
-            scene_free(&scn);
+            scene_free(scn);
+            free(scn);
             continue;
         }
-        double t0 = now_s();
-        if (want_depth && !depth_map) depth_map = (double *)malloc((size_t)width * height * sizeof(double));
-        if (!ndt_render_image_full(&scn, width, height, threads, aa_diff, aa_depth, stereo, specular, depth, rgba, depth_map)) return 1;
-        printf("rendering took %.3fs\n", now_s() - t0);
-        char dir[512], path[1024];
-        mkdir("images", 0700);
-        snprintf(dir, sizeof(dir), "images/%s", scn.name); mkdir(dir, 0700);
-        snprintf(dir, sizeof(dir), "images/%s/%id", scn.name, dims); mkdir(dir, 0700);
-        snprintf(dir, sizeof(dir), "images/%s/%id/%ix%i", scn.name, dims, width, height); mkdir(dir, 0700);
-        snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn.name, width, height, i);
-        write_ppm(path, rgba, width, height);
-        printf("\tsaved %s\n", path);
-        if (depth_map) {
-            /* dbl_image_normalize (image.c:1025-1065) stretches the map to 0..1 before it is saved (ndt.c:1010-1016) */
-            double lo = depth_map[0], hi = depth_map[0];
-            for (long k = 0; k < (long)width * height; ++k) {
-                if (depth_map[k] < lo) lo = depth_map[k];
-                if (depth_map[k] > hi) hi = depth_map[k];
-            }
-            double *norm = (double *)malloc((size_t)width * height * 4 * sizeof(double));
-            for (long k = 0; k < (long)width * height; ++k) {
-                const double v = hi > lo ? (depth_map[k] - lo) / (hi - lo) : 0.0;
-                norm[4 * k] = norm[4 * k + 1] = norm[4 * k + 2] = v;
-                norm[4 * k + 3] = 1.0;
-            }
-            mkdir("depth", 0700);
-            snprintf(path, sizeof(path), "depth/%s_%ix%i_%04i.ppm", scn.name, width, height, i);
-            write_ppm(path, norm, width, height);
-            printf("\tsaved %s\n", path);
-            free(norm);
-            if (raw_path) {
-                char dpath[1100];
-                snprintf(dpath, sizeof(dpath), "%s.depth", raw_path);
-                FILE *f = fopen(dpath, "wb");
-                if (f) { fwrite(depth_map, sizeof(double), (size_t)width * height, f); fclose(f); }
-            }
+        ++rendered;
+        if (workers) {
+            queue_push(scn, i);
+        } else {
+            if (!render_frame(scn, i)) return 1;
+            scene_free(scn);
+            free(scn);
         }
-        if (raw_path) {
-            FILE *f = fopen(raw_path, "wb");
-            if (f) { fwrite(rgba, sizeof(double), (size_t)width * height * 4, f); fclose(f); }
-        }
-        scene_free(&scn);
     }
-    free(rgba);
+    if (workers) {
+        queue_close();
+        for (int k = 0; k < jobs; ++k) pthread_join(workers[k], NULL);
+        free(workers);
+        if (worker_failed) return 1;
+    }
+    if (rendered > 1) printf("%d frames in %.3fs (%.2f frames/s)\n", rendered, now_s() - t_all, rendered / (now_s() - t_all));
     if (cleanup) cleanup();
     return 0;
 }

@@ -2,7 +2,8 @@
  * render on the GPU through the C ABI of include/ndt_hip.h.  No CPU rendering exists here. */
 #include "ndt_host_internal.h"
 
-static ndt_hip_ctx *g_ctx = NULL;
+/* one GPU context (stream + workspace) per host thread: frames rendered from different threads overlap on the GPU */
+static __thread ndt_hip_ctx *g_ctx = NULL;
 
 int ndt_render_image(scene *scn, int width, int height, int threads, int max_optic_depth, double *rgba)
 {

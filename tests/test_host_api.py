@@ -146,3 +146,22 @@ def test_driver_stereo_and_depth_flags(driver, tmp_path, name, flags):
         dm = np.fromfile(raw + ".depth").reshape(g.height, g.width)
         assert np.abs(dm - g.data["depth"]).max() < 1e-9
         assert len(list((tmp_path / "depth").glob("*.ppm"))) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
+def test_frames_in_flight_produce_the_same_images(driver, tmp_path):
+    """`ndt_hip -j K`: the scene program runs frame after frame on one thread, K workers (one GPU
+    context each) flatten, render and save -- the images must not depend on K."""
+    outs = []
+    for j in (1, 3):
+        d = tmp_path / ("j%d" % j)
+        d.mkdir()
+        cmd = [driver, "-s", os.path.join(REF_BIN, "hypercube.so"), "-d", "3", "-r", "96x64", "-l", "16", "-f", "30:35", "-j", str(j)]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        files = sorted(p for p in (d / "images").rglob("*.ppm"))
+        assert len(files) == 6
+        outs.append([p.read_bytes() for p in files])
+    assert outs[0] == outs[1]
+    assert len(set(outs[0])) == 6       # an animation: every frame differs
