@@ -50,6 +50,7 @@ struct SceneDesc {
     int off_cam;       // pos[N], img_orig[N], dir_x[N], dir_y[N], focal, ambient[3], background[4]
     int total_words;
     int mask_words;    // 64-bit words of visit mask per ray (kd-tree.c:600)
+    int kd_depth;      // deepest leaf of the kd-tree (root = 1): the traversal stack never holds more entries
 };
 
 // ------------------------------------------------------------------ vectNd.h
@@ -735,13 +736,22 @@ template <int MW> struct VisitMask {
 #define NDT_OCC(slot) do { } while (0)
 #endif
 
-template <int N, int MW>
+// Where the traversal stack lives.  Scratch (per-lane arrays in private memory) always works; LDS
+// (one slot per lane and level, [level][lane] so that lanes never share a bank) takes the push /
+// pop round trips out of the T phase when the workgroup's LDS has room for depth x lanes entries.
+struct KdStackLds {
+    double *tu;         // already offset by the lane: element d at [d * stride]
+    int *node;          // the PARENT of the pending far child: its split plane gives `a` back exactly (12 bytes per entry, not 20)
+    int stride;
+};
+
+template <int N, int MW, bool LSTACK = false>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
                       , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
 #endif
-                      )
+                      , KdStackLds ls = KdStackLds{})
 {
 #ifdef NDT_PHASE_TIMING
     unsigned long long ph_last = __builtin_readcyclecounter();
@@ -769,8 +779,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int l_obj = -1, l_prim = -1;
 
     // traversal state
-    int st_node[NDT_KD_STACK];
-    double st_a[NDT_KD_STACK], st_tu[NDT_KD_STACK];
+    int st_node[LSTACK ? 1 : NDT_KD_STACK];
+    double st_a[LSTACK ? 1 : NDT_KD_STACK], st_tu[LSTACK ? 1 : NDT_KD_STACK];
     int sp = 0;
     int node = 0;
     double ntl = 0, ntu = 0;
@@ -848,9 +858,24 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     done = true;
                 } else {
                     --sp;
-                    const int nf = st_node[sp];
-                    const double a = st_a[sp];
-                    ntu = st_tu[sp];
+                    int nf;
+                    double a;
+                    if (LSTACK) {
+                        // the entry names the parent; tp and the far child are recomputed from its record
+                        // with the operations of the push (same operands, same result)
+                        const int parent = ls.node[sp * ls.stride];
+                        ntu = ls.tu[sp * ls.stride];
+                        const ndt_v2d prec = blob_pair(blob, sd.off_kd + 2 * parent);
+                        const long long pw0 = __double_as_longlong(prec.x);
+                        const int pdim = (int)(pw0 & 0xffffffffll);
+                        const double pv_inv = v_pick<N>(v_inv, pdim);
+                        a = (prec.y - v_pick<N>(o, pdim)) * pv_inv;
+                        nf = (pv_inv < NDT_EPS2) ? parent + 1 : (int)(pw0 >> 32);
+                    } else {
+                        nf = st_node[sp];
+                        a = st_a[sp];
+                        ntu = st_tu[sp];
+                    }
                     node = nf & ~NDT_STACK_FLAG;
                     ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
                     // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
@@ -893,7 +918,9 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             node = far; have_node = true;               // far only, same interval
                         } else {
                             if (lt > tp) {
-                                st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; ++sp;    // far: (tp-EPS, tu), gate tp
+                                if (LSTACK) { ls.node[sp * ls.stride] = node; ls.tu[sp * ls.stride] = ntu; }
+                                else { st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; }
+                                ++sp;                                   // far: (tp-EPS, tu), gate tp
                             }
                             if (alive) { node = near; ntu = tp + NDT_EPS; have_node = true; }
                         }
@@ -901,7 +928,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
                         // by construction), kept for fidelity with kd-tree.c:555-565
                         if (o_i > boundary - NDT_EPS) {
-                            st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp;
+                            // (never taken: |v_inv| <= 1/EPS^2 by construction; the LDS stack has no form for this entry)
+                            if (!LSTACK) { st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp; }
                         }
                         if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
                     }

@@ -559,6 +559,7 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         if (max_depth > NDT_KD_STACK)
             return fail(NDT_E_UNSUPPORTED, "kd-tree depth %d exceeds the traversal stack (%d)", max_depth, NDT_KD_STACK);
     }
+    sd.kd_depth = max_depth;
     std::vector<int> new_index((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), -1);
     for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
     sd.n_kd_nodes = (int)order.size();

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 // queue (one atomic per batch), so a wavefront that drew cheap rays (sky) immediately takes
 // more work instead of idling until the expensive tiles finish.  Every wavefront exits when
 // the queue head passes the ray count.
-template <int MW, bool LDS>
+template <int MW, bool LDS, bool LSTACK = false>
 __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
@@ -213,6 +213,15 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         for (int i = threadIdx.x; i < sd.trace_words; i += blockDim.x) lds_blob[i] = gblob[i];
         __syncthreads();
         blob = lds_blob;
+    }
+    KdStackLds kstack{};
+    if (LSTACK) {
+        // behind the scene: [kd_depth][lanes] of tu (doubles) and parent node (ints)
+        double *base = lds_blob + ((sd.trace_words + 1) & ~1);
+        const int depth = sd.kd_depth + 1;
+        kstack.stride = blockDim.x;
+        kstack.tu = base + threadIdx.x;
+        kstack.node = (int *)(base + (size_t)depth * blockDim.x) + threadIdx.x;
     }
     VisitMask<MW> mask;
     mask.ext = nullptr;
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;     // keeps the loads alive
             prim = -1;
         } else
-        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ);
+        trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
         out_last = __builtin_readcyclecounter();
         if (ws.dbg && lane == __ffsll((long long)__ballot(1)) - 1) {
             // duration of this batch inside trace_kd: slowest batch of the launch (dbg[40 + is_shadow])
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             prim = -1;
         } else
 #endif
-        trace_kd<N, MW>(blob, sd, mask, o, v, lim, obj, prim);
+        trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
 #endif
 #ifdef NDT_TRACE_SKIP_KNOB
         if (job.skip_trace == 2 && obj == -1) continue;
@@ -418,7 +427,17 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
     if (tier == 0) {
         static const int extra_lds = env_int("NDT_TRACE_EXTRA_LDS", 0);   // experiment knob: lowers occupancy
         const size_t lds = (size_t)sd.trace_words * sizeof(double) + (size_t)extra_lds;
-        if (mask_words <= 1) {
+        // Traversal stack in LDS when it fits beside the scene: one workgroup of 768 lanes per CU (the scene is
+        // staged once instead of three times), 12 bytes per level and lane.  NDT_TRACE_LSTACK=0 switches back
+        // to the scratch stack with NDT_TRACE_BLOCK-sized workgroups (also what deeper trees / bigger scenes get).
+        static const int lstack_block = env_int("NDT_TRACE_LSTACK", NDT_TRACE_MAX_BLOCK);
+        const size_t lds_stack = ((size_t)((sd.trace_words + 1) & ~1) * 8) + (size_t)lstack_block * (sd.kd_depth + 1) * 12;
+        if (lstack_block >= 64 && mask_words <= 1 && lds_stack <= 160 * 1024) {
+            const int res = resident_blocks(k_trace<1, true, true>, lstack_block, lds_stack);
+            long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
+            if (nb > res) nb = res;
+            hipLaunchKernelGGL((k_trace<1, true, true>), dim3((unsigned)nb), dim3(lstack_block), lds_stack, s, blob, sd, ws, job);
+        } else if (mask_words <= 1) {
             static int res = 0;
             if (!res) res = resident_blocks(k_trace<1, true>, block, lds);
             if (blocks > res) blocks = res;
