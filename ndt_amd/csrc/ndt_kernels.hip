@@ -592,37 +592,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     int my_base = 0;
     if (my_total > 0) my_base = atomicAdd(&NDT_SEG_COUNTERS(ws, level)[lane], my_total);
     if (shaded) ws.sh_mask[g] = fire;
-#ifdef NDT_PHASE_TIMING
-    seg = __shfl(my_base, 0, 64) & 0;      // forces the atomic's round trip into section 2
-#endif
     NDT_SEC(2);
-    seg = 0;
-    for (int li = 0; li < sd.n_lights; ++li) {
-        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
-        const bool fires = (fire >> li) & 1ull;
-        const unsigned long long vote = __ballot(fires);
-        const int base = __shfl(my_base, seg, 64);
-        if (fires) {
-            int type;
-            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
-            ShadowSetup ss;
-            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
-            const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
-            const long long slot = (long long)seg * lr.seg_stride + idx;
-            ws.sh_idx[(long long)seg * ws.cap + g] = idx;
-            store_soa<N>(ws.so, ws.sh_cap, slot, so);
-            // point/spot: from the light along light_vec (ndt.c:211); directional: from the
-            // nudged hit point along rev_light (ndt.c:238)
-            if (type == NDT_LIGHT_DIRECTIONAL_)
-                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
-            else
-                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
-            ws.slim[slot] = ss.dist_limit;
-        }
-        ++seg;
-    }
-
-    NDT_SEC(3);
     // get_ray_color, ndt.c:381-430: spawn reflection / refraction.  The children depend on the
     // hit only, not on the lighting, so they are created here -- before the shadow rays of this
     // bounce are traced -- and the host traces them in the SAME launch as those shadow rays.
@@ -655,7 +625,9 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             if (refr_frac < (1.0 / 512.0) || depth_next <= 0) {
                 c_refr = -2;
             } else {
-                v_refract<N>(look, nrm, refr_ray, blob[mw + 6]);    // unitizes nrm; nothing reads it afterwards
+                double nrm_u[N];                                    // vectNd_refract unitizes the normal it is given (vectNd.c:155);
+                v_copy<N>(nrm_u, nrm);                              // the shadow rays below still need the original
+                v_refract<N>(look, nrm_u, refr_ray, blob[mw + 6]);
                 v_unitize<N>(refr_ray);
                 want_refr = true;
             }
@@ -669,8 +641,10 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
     const int base = wave_reserve(&ws.counters[0], total);
     if (total > 0 && (long long)base + total > ws.cap) {
+        // node pool overflow: flag it (the host renders the frame again with a larger pool), spawn nothing
         if (lane == 0) atomicOr(&ws.counters[2], 1);
-        return;
+        want_refl = false;
+        want_refr = false;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (want_refl) {
@@ -697,6 +671,34 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
         ws.sh_mask[c] = 0ull;
         ws.child_refr[g] = (int)c;
     }
+    NDT_SEC(3);
+    // shadow rays into their segments (the reservation above has had the whole spawn section to come back)
+    seg = 0;
+    for (int li = 0; li < sd.n_lights; ++li) {
+        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
+        const bool fires = (fire >> li) & 1ull;
+        const unsigned long long vote = __ballot(fires);
+        const int base = __shfl(my_base, seg, 64);
+        if (fires) {
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+            ShadowSetup ss;
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
+            const long long slot = (long long)seg * lr.seg_stride + idx;
+            ws.sh_idx[(long long)seg * ws.cap + g] = idx;
+            store_soa<N>(ws.so, ws.sh_cap, slot, so);
+            // point/spot: from the light along light_vec (ndt.c:211); directional: from the
+            // nudged hit point along rev_light (ndt.c:238)
+            if (type == NDT_LIGHT_DIRECTIONAL_)
+                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
+            else
+                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
+            ws.slim[slot] = ss.dist_limit;
+        }
+        ++seg;
+    }
+
     NDT_SEC(4);
     NDT_SEC_END(52);
 }
