@@ -160,7 +160,10 @@ typedef struct ndt_flat_scene {
 typedef struct ndt_render_params {
     int32_t width, height;
     int32_t max_optic_depth;    /* `-l`, default 128 (ndt.c:1413) */
-    int32_t samples;            /* must be 1: the deterministic path */
+    int32_t samples;            /* `-n`.  1 = the deterministic path.  > 1 = jittered samples + lens
+                                 * sampling + the adaptive loop (ndt.c:470-568) with a per-(pixel, sample) counter-based
+                                 * random stream: reproducible, independent of sharding, statistically equivalent to
+                                 * the reference's drand48 stream (mono planar camera, no recursive_aa, no depth map) */
     int32_t row_begin, row_step;
     int32_t specular;           /* 1 = specular_enabled (ndt.c:41) */
     int32_t profile;            /* 1 = bracket trace kernels with hipEvents (fills *_ms below) */

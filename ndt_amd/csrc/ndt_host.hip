@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, Scene
         const double gb0 = (fabs(l[1]) > fabs(l[2])) ? fabs(l[1]) : fabs(l[2]);
         const double lmax = (fabs(l[0]) > gb0) ? fabs(l[0]) : gb0;
         const bool finite = lmax <= 1.0e300;          // false for inf / nan: always take the exact path
-        for (int i = 0; i < 1 || (i < 10000 && clr_diff > max_diff); ++i) {
+        for (int i = 0; i < 1 || (!rg.raw_samples && i < 10000 && clr_diff > max_diff); ++i) {
             if (i > 1) {
                 const double ii = (double)i * (double)(i - 1);
                 const double est = lmax / ii;
@@ -1605,6 +1605,159 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
     return NDT_OK;
 }
 
+// ------------------------------------------------------------------ -n samples > 1 (ndt.c:470-568)
+//
+// Jittered samples inside the pixel + a lens sample per ray, the adaptive loop on top: at least
+// `samples` samples per pixel, then more while the running mean still moves by more than 1/256
+// (at most 10000).  The reference draws from one global drand48 stream in pixel order, which no
+// parallel renderer can follow; here every (pixel, sample) has its own counter-based stream, so the
+// image is reproducible and independent of sharding, and parity with the reference is statistical
+// (tests compare against the oracle, which follows the reference's stream exactly).
+// Round r renders sample r of every pixel that is still sampling, through the pipeline in list mode.
+
+__device__ __forceinline__ unsigned long long ns_mix(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull;                 // splitmix64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double ns_uniform(unsigned long long pixel, unsigned int round, unsigned int k)
+{
+    const unsigned long long h = ns_mix(ns_mix(pixel * 0x100000001b3ull + round) + k);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);         // [0, 1)
+}
+
+// sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
+__global__ void k_ns_samples(const int *active, int n_active, int width, int row_begin, int row_step, unsigned int round,
+                             double aperture, double *samples)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const int pix = active[a];
+    const int l = pix / width, i = pix % width;
+    const int j = row_begin + l * row_step;
+    const unsigned long long id = (unsigned long long)j * (unsigned long long)width + (unsigned long long)i;
+    const double dx = ns_uniform(id, round, 0), dy = ns_uniform(id, round, 1);
+    double ax, ay;
+    unsigned int k = 2;
+    do {        // reject samples outside the unit disk
+        ax = 2 * ns_uniform(id, round, k) - 1.0;
+        ay = 2 * ns_uniform(id, round, k + 1) - 1.0;
+        k += 2;
+    } while (ax * ax + ay * ay > 1.0 && k < 64);
+    double *q = samples + 4ll * a;
+    q[0] = i + dx;          // x = orig_x + dx/width
+    q[1] = j - dy;          // y = orig_y + dy/height, and y grows upwards
+    q[2] = ax * aperture;
+    q[3] = ay * aperture;
+}
+
+// get_pixel_color's loop body after the sample has been traced (ndt.c:553-567), and its continuation test
+__global__ void k_ns_accumulate(const int *active, int n_active, const double *colours, unsigned int round, int min_samples,
+                                double *acc, int *next, int *next_count)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const int pix = active[a];
+    const double *l = colours + 4ll * a;
+    double *t = acc + 5ll * pix;            // t_clr rgba + clr_diff
+    const int i = (int)round;
+    double clr_diff = t[4];
+    if (i > 1) {
+        const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+        const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+        const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+        const double gb = (dg > db) ? dg : db;
+        clr_diff = (dr > gb) ? dr : gb;
+    }
+    t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
+    t[4] = clr_diff;
+    const int done = i + 1;
+    if (done < min_samples || (done < 10000 && clr_diff > 1.0 / 256.0)) next[atomicAdd(next_count, 1)] = pix;
+}
+
+__global__ void k_ns_init(double *acc, int *active, int *taken, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    double *t = acc + 5 * i;
+    t[0] = t[1] = t[2] = t[3] = 0.0;
+    t[4] = 256.0;
+    active[i] = (int)i;
+    taken[i] = 0;
+}
+
+__global__ void k_ns_count(const int *active, int n_active, int *taken)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n_active) taken[active[a]] += 1;
+}
+
+__global__ void k_ns_finish(const double *acc, const int *taken, double *rgba, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const int n = taken[i] > 0 ? taken[i] : 1;
+    for (int c = 0; c < 4; ++c) rgba[4 * i + c] = acc[5 * i + c] / n;
+}
+
+static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total)
+{
+    hipStream_t s = ctx->stream;
+    const int W = p->width, H = p->height;
+    const int rows = ndt_hip_shard_rows(H, p->row_begin, p->row_step);
+    const long long n_pixels = (long long)rows * W;
+    if (n_pixels > 0x3fffffffLL) return fail(NDT_E_UNSUPPORTED, "image too large for one call");
+    AaBuffers buf;
+    int rc;
+    double *acc = nullptr, *samples = nullptr, *colours = nullptr;
+    int *list[2] = { nullptr, nullptr }, *taken = nullptr, *counter = nullptr;
+    if ((rc = buf.get(&acc, (size_t)n_pixels * 5))) return rc;
+    if ((rc = buf.get(&samples, (size_t)n_pixels * 4))) return rc;
+    if ((rc = buf.get(&colours, (size_t)n_pixels * 4))) return rc;
+    if ((rc = buf.get(&list[0], (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&list[1], (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&taken, (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&counter, 1))) return rc;
+    const unsigned g_all = (unsigned)((n_pixels + 255) / 256);
+    hipLaunchKernelGGL(k_ns_init, dim3(g_all), dim3(256), 0, s, acc, list[0], taken, n_pixels);
+    int n_active = (int)n_pixels;
+    for (unsigned int round = 0; n_active > 0 && round < 10000; ++round) {
+        const unsigned g_act = (unsigned)((n_active + 255) / 256);
+        hipLaunchKernelGGL(k_ns_samples, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, W, p->row_begin, p->row_step, round,
+                           ctx->aperture_radius, samples);
+        RenderGeom gs{};
+        gs.samples = samples;
+        gs.n_samples = n_active;
+        gs.n_primary = (n_active + 63) & ~63;
+        gs.width = n_active;
+        gs.rows = 1;
+        gs.max_depth = p->max_optic_depth;
+        gs.specular = p->specular ? 1 : 0;
+        gs.img_w = W;
+        gs.img_h = H;
+        gs.aspect_w = W;
+        gs.aspect_h = H;
+        gs.eye = 1;
+        gs.lens = 1;
+        gs.raw_samples = 1;
+        ndt_render_stats st{};
+        if ((rc = render_pass(ctx, gs, p->profile != 0, colours, st))) return rc;
+        add_stats(total, st);
+        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ns_count, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, taken);
+        hipLaunchKernelGGL(k_ns_accumulate, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, colours, round, p->samples, acc,
+                           list[(round + 1) & 1], counter);
+        HIP_TRY(hipMemcpyAsync(&n_active, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_ns_finish, dim3(g_all), dim3(256), 0, s, acc, taken, (double *)d_rgba, n_pixels);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return NDT_OK;
+}
+
 // true anaglyph (ndt.c:643-647): red = luminance of the left eye's colour, blue = of the right eye's
 __global__ void k_anaglyph(const double *left, const double *right, double *out, long long n_pixels)
 {
@@ -1622,7 +1775,11 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
 {
     if (!ctx || !p || !d_rgba) return fail(NDT_E_INVALID, "NULL argument");
     if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
-    if (p->samples != 1) return fail(NDT_E_UNSUPPORTED, "samples=%d: only the deterministic samples=1 path is implemented", p->samples);
+    if (p->samples < 1) return fail(NDT_E_INVALID, "samples=%d", p->samples);
+    if (p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
+        return fail(NDT_E_UNSUPPORTED, "samples > 1 is implemented for the mono planar camera without recursive anti-aliasing or a depth map");
+    if (p->samples > 1 && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
+        return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
     if (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)
         return fail(NDT_E_UNSUPPORTED, "stereo mode %d (mono, side by side, over/under and anaglyph are implemented)", p->stereo);
@@ -1656,6 +1813,8 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     // the reference's switch: -a with depth >= 0 and diff < 256 resamples, otherwise the first pass is copied (ndt.c:1040)
     if (p->recursive_aa) {
         rc = render_antialiased(ctx, p, d_rgba, st);
+    } else if (p->samples > 1) {
+        rc = render_sampled(ctx, p, d_rgba, st);
     } else {
         RenderGeom rg{};
         rg.width = p->width;

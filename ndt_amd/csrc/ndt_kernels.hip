@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
     int eye = rg.eye;
     if (rg.samples) {
         live = g < rg.n_samples;
-        ip = live ? rg.samples[2 * g] : 0.0;
-        jp = live ? rg.samples[2 * g + 1] : 0.0;
+        const int rec = rg.lens ? 4 : 2;
+        ip = live ? rg.samples[rec * g] : 0.0;
+        jp = live ? rg.samples[rec * g + 1] : 0.0;
     } else {
         const int tile = (int)(g >> 6), lane = (int)(g & 63);
         const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
@@ -186,6 +187,16 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
         v_sub<N>(cam, pz, cam);
         v_add<N>(cam, rx, cam);
         v_add<N>(cam, rz, cam);
+    }
+    if (rg.samples && rg.lens) {
+        // lens sample for depth of field (ndt.c:527-542): offsets already scaled by the aperture radius
+        double ax[N];
+        blob_vec<N>(blob, ext + 3 + 2 * N, ax);
+        v_scale<N>(ax, rg.samples[4 * g + 2], temp);
+        v_add<N>(cam, temp, cam);
+        blob_vec<N>(blob, ext + 3 + 3 * N, ax);
+        v_scale<N>(ax, rg.samples[4 * g + 3], temp);
+        v_add<N>(cam, temp, cam);
     }
     v_sub<N>(pixel, cam, look);
     v_unitize<N>(look);

@@ -68,6 +68,8 @@ struct RenderGeom {
     int aspect_w, aspect_h;     // cam.dirX *= aspect_w/aspect_h            (ndt.c:926)
     const double *samples;      // list mode: (i, j) per sample, in pixels of the img_w x img_h image
     int n_samples;
+    int lens;                   // list mode: records are (i, j, lx, ly): the eye is moved by lx*localX + ly*localY (ndt.c:538-541)
+    int raw_samples;            // list mode: one colour per sample as traced (-n > 1), no replay of the samples=1 loop
     int stereo;                 // ndt_stereo_mode: 1 side by side, 2 over/under split the image between the eyes (ndt.c:590-612)
     int eye;                    // 0 left, 1 centre, 2 right: the eye when stereo does not split the image (anaglyph renders twice)
     int want_depth;             // record 1/distance of the primary hits (depth maps, ndt.c:362-373)

@@ -120,8 +120,8 @@ class NdtHip:
         self._check(self.lib.ndt_hip_upload_scene(self.ctx, fs.byref()))
         self.scene = fs          # keep the arrays alive; also gives dims
 
-    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0):
-        p = RenderParams(width, height, depth, 1, row_begin, row_step, specular, profile)
+    def params(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0, samples=1):
+        p = RenderParams(width, height, depth, int(samples), row_begin, row_step, specular, profile)
         p.stereo = int(stereo)      # ndt_stereo_mode: 0 mono, 1 side by side, 2 over/under, 3 anaglyph
         if aa is not None:
             # Whitted's recursive anti-aliasing, `-a diff,depth` (ndt.c:655-733)
@@ -129,11 +129,11 @@ class NdtHip:
         return p
 
     def render(self, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0,
-               depth_map=False):
+               depth_map=False, samples=1):
         """render_image for a row shard; returns ((rows, width, 4) float64 host array, RenderStats).
         aa = (aa_diff, aa_depth) switches recursive anti-aliasing on; stereo = ndt_stereo_mode;
         depth_map=True returns (rgba, (rows, width) depth map, stats)."""
-        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa, stereo)
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa, stereo, samples)
         if depth_map:
             rows = shard_rows(height, row_begin, row_step)
             out = np.zeros((rows, width, 4), dtype=np.float64)
@@ -148,9 +148,10 @@ class NdtHip:
         self._check(self.lib.ndt_hip_render(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
         return out, st
 
-    def render_device(self, d_rgba_ptr, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None):
+    def render_device(self, d_rgba_ptr, width, height, depth, row_begin=0, row_step=1, specular=1, profile=0, aa=None, stereo=0,
+                      samples=1):
         """Same, output left in HBM at raw device pointer `d_rgba_ptr` (rows*width*4 doubles)."""
-        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa)
+        p = self.params(width, height, depth, row_begin, row_step, specular, profile, aa, stereo, samples)
         st = RenderStats()
         self._check(self.lib.ndt_hip_render_device(self.ctx, C.byref(p), C.c_void_p(d_rgba_ptr), C.byref(st)))
         return st

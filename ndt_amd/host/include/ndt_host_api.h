@@ -393,9 +393,10 @@ int ndt_render_image(scene *scn, int width, int height, int threads, int max_opt
 /* the same with Whitted's recursive anti-aliasing, the reference's `-a diff,depth` (ndt.c:1453-1465); aa_depth < 0 = off */
 int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int max_optic_depth,
                         double *rgba);
-/* ... and with everything render_image takes (ndt.c:900): stereo mode (-m), specular_enabled (-p clears it), depth map (-z) */
-int ndt_render_image_full(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int stereo, int specular,
-                          int max_optic_depth, double *rgba, double *depth);
+/* ... and with everything render_image takes (ndt.c:900): samples (-n), stereo mode (-m), specular_enabled (-p clears it),
+ * depth map (-z) */
+int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
+                          int specular, int max_optic_depth, double *rgba, double *depth);
 
 #ifdef __cplusplus
 }

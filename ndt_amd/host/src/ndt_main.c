@@ -42,7 +42,7 @@ static int write_ppm(const char *path, const double *rgba, int w, int h)
 
 /* ---- one frame: flatten, upload, render, save (what follows scene_setup in the reference's frame loop) */
 static struct {
-    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth;
+    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth, samples;
     const char *raw_path;
 } job_opts;
 
@@ -52,8 +52,8 @@ static int render_frame(scene *scn, int i)
     double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
     double *depth_map = job_opts.want_depth ? (double *)malloc((size_t)width * height * sizeof(double)) : NULL;
     double t0 = now_s();
-    if (!ndt_render_image_full(scn, width, height, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth, job_opts.stereo,
-                               job_opts.specular, job_opts.depth, rgba, depth_map)) {
+    if (!ndt_render_image_full(scn, width, height, job_opts.samples, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth,
+                               job_opts.stereo, job_opts.specular, job_opts.depth, rgba, depth_map)) {
         free(rgba);
         free(depth_map);
         return 0;
@@ -173,12 +173,13 @@ int main(int argc, char **argv)
     int depth = 128, threads = 1;
     int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
     int jobs = 1;           /* -j: frames in flight */
+    int samples = 1;        /* -n (ndt.c:1574-1577) */
     int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
                                         { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
     int ch;
-    while ((ch = getopt_long(argc, argv, "a:d:r:f:j:l:m:3:ps:t:u:o:zh", longopts, NULL)) != -1) {
+    while ((ch = getopt_long(argc, argv, "a:d:r:f:j:l:m:3:n:ps:t:u:o:zh", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
         switch (ch) {
         case 'a':       /* -a diff,depth (ndt.c:1453-1465); defaults 20,4 */
@@ -214,6 +215,7 @@ int main(int argc, char **argv)
             default: stereo = 0; printf("stereo = MONO\n"); break;
             }
             break;
+        case 'n': samples = atoi(optarg); printf("samples = %i\n", samples); break;
         case 'p': specular = 0; printf("disabling specular highlights.\n"); break;
         case 'z': want_depth = 1; printf("record_depth_map = yes\n"); break;
         case 's': scene_path = optarg; break;
@@ -224,7 +226,7 @@ int main(int argc, char **argv)
         case 1001: raw_path = optarg; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-a diff,depth] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+                            "          [-a diff,depth] [-n samples] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -253,7 +255,7 @@ int main(int argc, char **argv)
 
     job_opts.dims = dims; job_opts.width = width; job_opts.height = height; job_opts.depth = depth; job_opts.threads = threads;
     job_opts.aa_diff = aa_diff; job_opts.aa_depth = aa_depth; job_opts.stereo = stereo; job_opts.specular = specular;
-    job_opts.want_depth = want_depth; job_opts.raw_path = raw_path;
+    job_opts.want_depth = want_depth; job_opts.raw_path = raw_path; job_opts.samples = samples;
     /* -j K: K frames in flight.  The scene program runs on this thread, frame after frame (it may
      * keep state between frames, ndt.c:1818-1825); everything after it -- bounding spheres, kd-tree,
      * upload, render, image files -- happens on K worker threads, each with its own GPU context.

@@ -14,13 +14,13 @@ int ndt_render_image(scene *scn, int width, int height, int threads, int max_opt
 int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int max_optic_depth,
                         double *rgba)
 {
-    return ndt_render_image_full(scn, width, height, threads, aa_diff, aa_depth, 0, 1, max_optic_depth, rgba, NULL);
+    return ndt_render_image_full(scn, width, height, 1, threads, aa_diff, aa_depth, 0, 1, max_optic_depth, rgba, NULL);
 }
 
-/* everything render_image takes (ndt.c:900): stereo = the reference's stereo_mode (MONO .. ANAGLYPH_3D),
- * specular = specular_enabled (`-p` clears it), depth = the depth map of `-z` (width*height doubles) or NULL */
-int ndt_render_image_full(scene *scn, int width, int height, int threads, int aa_diff, int aa_depth, int stereo, int specular,
-                          int max_optic_depth, double *rgba, double *depth)
+/* everything render_image takes (ndt.c:900): samples = `-n`, stereo = the reference's stereo_mode (MONO ..
+ * ANAGLYPH_3D), specular = specular_enabled (`-p` clears it), depth = the depth map of `-z` (width*height doubles) or NULL */
+int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
+                          int specular, int max_optic_depth, double *rgba, double *depth)
 {
     (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
     char err[256];
@@ -38,7 +38,7 @@ int ndt_render_image_full(scene *scn, int width, int height, int threads, int aa
     } else {
         ndt_render_params p;
         memset(&p, 0, sizeof(p));
-        p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = 1;
+        p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = samples > 1 ? samples : 1;
         p.row_begin = 0; p.row_step = 1; p.specular = specular;
         p.stereo = stereo;
         if (aa_depth >= 0 && aa_diff < 256) {       /* ndt.c:1040: otherwise the first pass is the image */

@@ -998,6 +998,8 @@ typedef struct {
     unsigned char *mask;
     ray_counts cnt;
     int specular;
+    int samples;            /* `-n`: > 1 = jittered samples + lens sampling with drand48 (ndt.c:505-542) */
+    double pix_w, pix_h;    /* 1/width, 1/height of the image being rendered (ndt.c:482-483) */
 } tctx;
 
 typedef struct { double r, g, b, a; } pix;
@@ -1291,7 +1293,10 @@ static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_opt
     const pscene *S = T->S;
     int n = S->n;
     double look[ND], pixel[ND], virtCam[ND];
-    int min_samples = 1;
+    const int samples = T->samples > 1 ? T->samples : 1;
+    if (samples > 1) literal = 1;              /* every sample is a different ray */
+    const double orig_x = x, orig_y = y;
+    int min_samples = samples;
     int max_samples = 10000;
     double max_diff = 1.0 / 256.0;
     double clr_diff = 256;
@@ -1302,11 +1307,34 @@ static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_opt
     for (int i = 0; i < min_samples || (i < max_samples && clr_diff > max_diff); ++i) {
         if (i == 0 || literal) {
             v_copy(virtCam, mode == CAM_LEFT ? S->cam_left_eye : mode == CAM_RIGHT ? S->cam_right_eye : S->cam_pos, n);   /* ndt.c:491-502 */
+            if (samples > 1) {
+                /* jitter inside the pixel (ndt.c:505-514); the reference's global drand48 stream */
+                double dx = drand48();
+                double dy = drand48();
+                x = orig_x + dx * T->pix_w;
+                y = orig_y + dy * T->pix_h;
+            }
             camera_target_point(S, x, y, S->fs->cam_focal_distance, pixel);
             if ((S->fs->cam_type == 1 || S->fs->cam_type == 2) && mode != CAM_CENTER) {
                 /* VR: the eye goes round the centre with the view direction (ndt.c:519-525) */
                 double azi = x * S->fs->cam_h_fov;
                 v_rotate2(virtCam, S->cam_pos, S->cam_local_x, S->cam_local_z, azi, virtCam, n);
+            }
+            if (samples > 1) {
+                /* lens sample for depth of field (ndt.c:527-542): rejection in the unit disk, also drawn
+                 * when the aperture is 0 (the offsets are then zero vectors) */
+                double ax, ay;
+                do {
+                    ax = 2 * drand48() - 1.0;
+                    ay = 2 * drand48() - 1.0;
+                } while (ax * ax + ay * ay > 1.0);
+                if (S->cam_local_x && S->cam_local_y) {
+                    double temp[ND];
+                    v_scale(S->cam_local_x, ax * S->fs->cam_aperture_radius, temp, n);
+                    v_add(virtCam, temp, virtCam, n);
+                    v_scale(S->cam_local_y, ay * S->fs->cam_aperture_radius, temp, n);
+                    v_add(virtCam, temp, virtCam, n);
+                }
             }
             v_sub(pixel, virtCam, look, n);
             l_clr.r = l_clr.g = l_clr.b = 0.0;
@@ -1366,6 +1394,7 @@ static void one_eye(job *J, tctx *T, double x, double y, pix *clr, int mode, dou
     int k = 0;
     ray_counts b = T->cnt;
     get_pixel_color_m(T, x, y, clr, J->p->max_optic_depth, J->literal, &k, mode, depth);
+    if (T->samples > 1) k = 1;      /* every sample was a ray of its own */
     J->unique.primary += (T->cnt.primary - b.primary) / k;
     J->unique.secondary += (T->cnt.secondary - b.secondary) / k;
     J->unique.shadow += (T->cnt.shadow - b.shadow) / k;
@@ -1410,6 +1439,9 @@ static void tctx_open(tctx *T, job *J)
     T->mask = (unsigned char *)malloc((size_t)(J->S->n_items > 0 ? J->S->n_items : 1));
     memset(&T->cnt, 0, sizeof(T->cnt));
     T->specular = J->p->specular;
+    T->samples = J->p->samples;
+    T->pix_w = 1.0 / (J->p->width + (J->p->recursive_aa ? 1 : 0));
+    T->pix_h = 1.0 / (J->p->height + (J->p->recursive_aa ? 1 : 0));
 }
 
 /* render_lines_thread / render_line, ndt.c:803 / 735 */
@@ -1562,8 +1594,11 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
         if ((L->type == NDT_LIGHT_POINT || L->type == NDT_LIGHT_SPOT) && L->pos_off < 0) return NDT_E_INVALID;
         if ((L->type == NDT_LIGHT_DIRECTIONAL || L->type == NDT_LIGHT_SPOT) && L->dir_off < 0) return NDT_E_INVALID;
     }
-    if (p && (p->samples != 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
+    if (p && (p->samples < 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
         return NDT_E_INVALID;
+    /* samples > 1: jitter + lens sampling from drand48 (ndt.c:505-542); not combined with the other modes here */
+    if (p && p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO)) return NDT_E_UNSUPPORTED;
+    if (p && p->samples > 1 && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
     if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)) return NDT_E_UNSUPPORTED;
     if (p && p->stereo != NDT_STEREO_MONO && p->recursive_aa) return NDT_E_UNSUPPORTED;
     /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
@@ -1586,6 +1621,14 @@ static void run_jobs(job *jobs, int threads, void *(*fn)(void *))
 /* render_image, ndt.c:900.  flags bit0: literal re-sampling (trace all k samples like the
  * reference; only changes run time and nothing else).  stats->rays_* = unique rays,
  * stats->rays_ref_equiv = what the reference's trace_kd counter reads. */
+/* samples > 1: the *rand48 state the next render starts from (the reference's scene programs draw from the
+ * same stream before the render does; the fixtures record where it stood) */
+static unsigned short g_seed48[3] = { 0x330E, 0xABCD, 0x1234 };     /* glibc's state in a fresh process */
+void ndt_oracle_set_seed48(unsigned short s0, unsigned short s1, unsigned short s2)
+{
+    g_seed48[0] = s0; g_seed48[1] = s1; g_seed48[2] = s2;
+}
+
 int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p, double *rgba, double *depth,
                             ndt_render_stats *stats, int threads, int flags);
 int ndt_oracle_render(const ndt_flat_scene *fs, const ndt_render_params *p, double *rgba, ndt_render_stats *stats,
@@ -1605,6 +1648,13 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
     rc = prepare_scene(fs, &S);
     if (rc != NDT_OK) return rc;
     if (threads < 1) threads = 1;
+    if (p->samples > 1) {
+        /* the random numbers come from one global stream in pixel order: one thread, starting where the
+         * reference run that made the fixture stood (ndt_oracle_set_seed48) */
+        unsigned short x0[3] = { g_seed48[0], g_seed48[1], g_seed48[2] };
+        seed48(x0);
+        threads = 1;
+    }
     v_scale(S.cam_dir_x, p->width / (double)p->height, S.cam_dir_x, S.n);      /* ndt.c:926 */
     job *jobs = (job *)calloc((size_t)threads, sizeof(job));
     struct timeval t0, t1;

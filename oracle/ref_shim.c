@@ -286,13 +286,14 @@ int main(int argc, char **argv)
     const char *aa = arg_str(argc, argv, "--aa", NULL);
     const char *yaml_out = arg_str(argc, argv, "--yaml-out", NULL);
     int stereo = atoi(arg_str(argc, argv, "--stereo", "0"));     /* stereo_mode, ndt.c:46-48 */
+    int samples = atoi(arg_str(argc, argv, "--samples", "1"));   /* `-n`: > 1 draws from drand48, run with --threads 1 */
     const char *depth_out = arg_str(argc, argv, "--depth-out", NULL);
     scene_v2 = arg_flag(argc, argv, "--scene-v2");
     if (!objdir || !scene_so || width < 1 || height < 1) {
         fprintf(stderr, "usage: ndt_ref_shim --objects DIR --scene X.so --dims N [--frame F] [--config S] --res WxH\n"
                         "       [--threads T] [--depth L] [--scene-out F] [--fb-out F] [--rays-in F --rays-out F]\n"
                         "       [--tmp DIR] [--no-render] [--aa DIFF,DEPTH] [--yaml-out F]\n"
-                        "       [--stereo MODE] [--depth-out F] [--scene-v2]\n");
+                        "       [--stereo MODE] [--depth-out F] [--scene-v2] [--samples N]\n");
         return 2;
     }
 
@@ -410,6 +411,15 @@ int main(int argc, char **argv)
         snprintf(name, sizeof(name), "%s/ndt_ref_shim_%d.jpg", tmpdir, (int)getpid());
         image_t img;
         dbl_image_init(&img);
+        {
+            /* the state of the *rand48 stream the render starts from (scene programs draw from it too,
+             * e.g. scenes/random.c:51): seed48 hands back the old state, which is put straight back */
+            unsigned short probe[3] = { 0, 0, 0 }, keep[3];
+            unsigned short *old = seed48(probe);
+            keep[0] = old[0]; keep[1] = old[1]; keep[2] = old[2];
+            seed48(keep);
+            printf("ref_shim: seed48 %u %u %u\n", keep[0], keep[1], keep[2]);
+        }
         n_trace_closest = n_trace_shadow = 0;
         counting = 1;
         double t0 = now_s();
@@ -417,7 +427,7 @@ int main(int argc, char **argv)
         snprintf(dname, sizeof(dname), "%s/ndt_ref_shim_depth_%d.jpg", tmpdir, (int)getpid());
         image_t dimg;
         dbl_image_init(&dimg);
-        render_image(&scn, name, depth_out ? dname : NULL, width, height, 1, stereo, threads, 20, 4, max_depth, &img,
+        render_image(&scn, name, depth_out ? dname : NULL, width, height, samples, stereo, threads, 20, 4, max_depth, &img,
                      depth_out ? &dimg : NULL);
         double t1 = now_s();
         counting = 0;

@@ -32,7 +32,7 @@ class Oracle:
         self.lib.ndt_oracle_trace_rays.restype = C.c_int
 
     def render(self, fs, width, height, depth, row_begin=0, row_step=1, threads=None, literal=False, specular=1, aa=None,
-               stereo=0, depth_map=False):
+               stereo=0, depth_map=False, samples=1, seed48=None):
         """aa = (aa_diff, aa_depth) switches Whitted's recursive anti-aliasing on (-a diff,depth);
         stereo = ndt_stereo_mode; depth_map=True also returns the 1/distance map: (rgba, depth, stats)."""
         from ndt_amd import shard_rows
@@ -41,6 +41,9 @@ class Oracle:
         if aa is not None:
             p.recursive_aa, p.aa_diff, p.aa_depth = 1, aa[0], aa[1]
         p.stereo = stereo
+        p.samples = samples
+        if seed48 is not None:
+            self.lib.ndt_oracle_set_seed48(C.c_ushort(seed48[0]), C.c_ushort(seed48[1]), C.c_ushort(seed48[2]))
         st = RenderStats()
         out = np.zeros((rows, width, 4), dtype=np.float64)
         dm = np.zeros((rows, width), dtype=np.float64) if depth_map else None
@@ -107,4 +110,5 @@ KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c
 FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
+SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof"]       # -n samples > 1 (meta: "samples")
 VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

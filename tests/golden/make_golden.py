@@ -82,6 +82,10 @@ CASES = {
     "pano_zoo5d_sbs": dict(scene="parity_zoo", dims=5, res=(64, 32), depth=5, fb=True, kat=0, v2=True, config="pano",
                            stereo=1),
     "depth_c3_random4d": dict(scene="random", dims=4, res=(64, 36), depth=4, fb=True, kat=0, v2=True, depth_map=True),
+    # -n samples > 1: jittered samples + lens sampling from the global drand48 stream (ndt.c:505-542), one thread,
+    # fresh process (default seed): reproducible, and the oracle walks the same stream
+    "ns_c3_random4d": dict(scene="random", dims=4, res=(32, 18), depth=4, fb=True, kat=0, samples=4, share_scene="c3_random4d"),
+    "ns_zoo4d_dof": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, samples=6, v2=True, config="dof"),
 }
 
 
@@ -96,6 +100,9 @@ def run_shim(args):
     m = re.search(r"ref_shim: aa_diff (\d+) aa_depth (\d+) pixels_resampled (\d+) rays_pass1 (\d+)", out)
     if m:
         info["aa_diff"], info["aa_depth"], info["pixels_resampled"], info["rays_pass1"] = (int(m.group(i)) for i in (1, 2, 3, 4))
+    m = re.search(r"ref_shim: seed48 (\d+) (\d+) (\d+)", out)
+    if m:
+        info["seed48"] = [int(m.group(i)) for i in (1, 2, 3)]
     m = re.search(r"ref_shim: rays_closest (\d+) rays_shadow (\d+) rays_total (\d+)", out)
     if m:
         info["rays_closest"], info["rays_shadow"], info["rays_total"] = (int(m.group(i)) for i in (1, 2, 3))
@@ -185,6 +192,10 @@ def generate(name, case):
             meta["stereo"] = case["stereo"]
         if case.get("depth_map"):
             args += ["--depth-out", os.path.join(tmp, "depth.bin")]
+        if case.get("samples"):
+            args += ["--samples", str(case["samples"])]
+            args[args.index("--threads") + 1] = "1"
+            meta["samples"] = case["samples"]
         if case["kat"]:
             rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"])
             rays.tofile(os.path.join(tmp, "rays.bin"))

@@ -60,6 +60,11 @@ int scene_setup(scene *scn, int dims, int frame, int frames, char *config)
     camera_set_aim(&scn->cam, &p, &q, &d, 0.1 * frame);
     /* config "vr" / "pano": spherical / cylindrical screen (camera.c:506-555) with fields of view that
      * keep the whole zoo in the picture */
+    /* config "dof": a lens (depth of field is sampled when -n > 1, ndt.c:527-542) focused short of the zoo */
+    if (config && strstr(config, "dof")) {
+        scn->cam.aperture_radius = 0.35;
+        scn->cam.focal_distance = 38.0;
+    }
     if (config && strstr(config, "vr")) {
         scn->cam.type = CAMERA_VR;
         scn->cam.hFov = 1.9;

@@ -9,7 +9,7 @@ may differ in the last ulps, hence TOL_TIGHT is what we actually expect and TOL_
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -223,3 +223,31 @@ def test_stereo_needs_the_eyes(gpu):
     gpu.upload_scene(g.scene)
     with pytest.raises(NdtHipError):
         gpu.render(32, 32, 4, stereo=1)
+
+
+@pytest.mark.parametrize("name", SAMPLED_CASES)
+def test_jittered_samples_statistically_match_the_oracle(gpu, oracle, name):
+    """`-n samples` > 1: jitter + lens sampling + adaptive loop.  The reference draws from one global
+    drand48 stream in pixel order (the oracle follows it exactly, test_oracle_golden.py); the device
+    uses its own per-(pixel, sample) streams, so the two are two estimates of the same image: with S
+    samples per pixel the difference behaves like sampling noise, and shrinks when S grows."""
+    g = golden(name)
+    gpu.upload_scene(g.scene)
+    errs = []
+    for S in (8, 128):
+        want, so = oracle.render(g.scene, g.width, g.height, g.depth, samples=S, seed48=g.meta["seed48"])
+        out, st = gpu.render(g.width, g.height, g.depth, samples=S)
+        assert st.rays_primary >= S * g.width * g.height        # at least S samples everywhere
+        d = np.abs(out[..., :3] - want[..., :3])
+        errs.append(d.mean())
+        assert np.abs(out[..., 3] - want[..., 3]).mean() < 0.05
+        # unbiased: the image means agree much better than single pixels do
+        assert abs(out[..., :3].mean() - want[..., :3].mean()) < 0.01
+    assert errs[1] < 0.6 * errs[0], errs            # noise, not bias: it goes down with more samples
+    assert errs[1] < 0.02, errs
+    # same call, same image; and sharding does not change it
+    again, _ = gpu.render(g.width, g.height, g.depth, samples=8)
+    first, _ = gpu.render(g.width, g.height, g.depth, samples=8)
+    assert np.array_equal(again, first)
+    part, _ = gpu.render(g.width, g.height, g.depth, samples=8, row_begin=1, row_step=2)
+    assert np.array_equal(part, first[1::2])

@@ -7,7 +7,7 @@ same glibc libm, no FMA, SSE lane-pair dot order.
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES
+from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -104,5 +104,18 @@ def test_stereo_vr_pano_and_depth_maps(oracle, name):
         assert (dm > 0).any()
     else:
         out, st = oracle.render(g.scene, g.width, g.height, g.depth, stereo=stereo)
+    assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+@pytest.mark.parametrize("name", SAMPLED_CASES)
+def test_jittered_samples_and_lens_bit_exact(oracle, name):
+    """`-n samples` > 1 (ndt.c:505-542): jitter inside the pixel and a lens sample per ray, both from the
+    global drand48 stream.  The reference run that made the fixture was single-threaded and recorded
+    where the stream stood when the render began (scene programs draw from it too); the oracle starts
+    there and walks the pixels in the same order, so it draws the same numbers: same image, same
+    trace_kd count."""
+    g = golden(name)
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"])
     assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
     assert st.rays_ref_equiv == g.meta["rays_total"]
