@@ -13,8 +13,9 @@ scene is the committed fixture tests/golden/c3_random4d.ndtscene.gz (flattened f
 compiled reference), i.e. synthetic data.
 N>1: the same scene and camera; the frame grows to N x (1920x1080) pixels at the same aspect
 ratio (N=4 is exactly configs[3]'s 3840x2160), rows are dealt cyclically to the ranks like the
-reference's MPI_ROW mode (ndt.c:812-820) and one RCCL gather over xGMI assembles the double
-image on rank 0 -- per-GPU work is fixed, so "scaling": "weak".
+reference's MPI_ROW mode (ndt.c:812-820) and one RCCL gather over xGMI assembles the final
+8-bit image on rank 0 (--gather f64: the double framebuffer) -- per-GPU work is fixed, so
+"scaling": "weak".
 
 `value` counts rays ACTUALLY traced on the GPUs (one trace_kd query each).  The reference
 re-traces every pixel's identical ray tree k = 3..18 times (adaptive loop, ndt.c:488; SURVEY
@@ -126,7 +127,9 @@ def main():
     ap.add_argument("--workload", default="random4d", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="pthreads for the reference CPU baseline")
-    ap.add_argument("--gather", default="f64", choices=["f64", "rgba8"], help="what the image gather moves")
+    ap.add_argument("--gather", default="rgba8", choices=["f64", "rgba8"],
+                    help="what the image gather moves: rgba8 = the final 8-bit image (pixel_d2c on the device, what the "
+                         "reference writes to disk), f64 = the double framebuffer (8x the bytes over xGMI)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 code path on a "
                          "one-GPU box (all ranks share device 0, shards staged through host memory)")

@@ -40,9 +40,14 @@ def _worker(rank, world, port, height, width, depth, name, out_path):
     cnt = torch.tensor([float(st.rays_ref_equiv)], dtype=torch.float64)
     dist.all_reduce(cnt)
     img = rg.assemble()
+    # the quantised image (what the reference writes to disk, pixel_d2c) gathered the same way: bench.py's default
+    rg8 = RowGather(height, width, 4, torch.uint8, "cpu", rank, world, dist)
+    rg8.local[:n] = torch.from_numpy(Oracle().quantize(rows))
+    img8 = rg8.assemble()
     if rank == 0:
         np.save(out_path, img.numpy())
         np.save(out_path + ".cnt.npy", cnt.numpy())
+        np.save(out_path + ".u8.npy", img8.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,6 +62,7 @@ def test_two_ranks_assemble_the_reference_frame(tmp_path, oracle, height):
     want, st = oracle.render(g.scene, g.width, height, g.depth)
     assert np.array_equal(got, want)
     assert float(np.load(out + ".cnt.npy")[0]) == float(st.rays_ref_equiv)
+    assert np.array_equal(np.load(out + ".u8.npy"), oracle.quantize(want))
     if height == g.height:
         assert np.array_equal(got, g.data["fb"])        # the compiled reference's framebuffer
 
