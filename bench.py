@@ -187,6 +187,9 @@ def main():
                 if rehearsal:
                     rg64.local.copy_(local)
                 rg64.assemble()
+            # the gather runs on torch's collective stream, the next frame on the context's own stream:
+            # the shard buffers must not be rewritten before the gather has read them
+            torch.cuda.synchronize()
         return st
 
     def fence():
