@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NDT_HIP_ABI_VERSION 2
+#define NDT_HIP_ABI_VERSION 3
 
 /* Dimensions the gfx950 kernels are instantiated for.  The reference accepts any N >= 3
  * (ndt.c:1450 `-d`); BASELINE.json's configs span 3..8. */
@@ -62,8 +62,8 @@ enum ndt_light_type {
     NDT_LIGHT_POINT       = 1,
     NDT_LIGHT_DIRECTIONAL = 2,
     NDT_LIGHT_SPOT        = 3,
-    NDT_LIGHT_DISK        = 4,  /* area lights need the RNG path: NDT_E_UNSUPPORTED for now */
-    NDT_LIGHT_RECT        = 5
+    NDT_LIGHT_DISK        = 4,  /* area lights: a random point of the disk / rectangle per shading evaluation */
+    NDT_LIGHT_RECT        = 5   /* (ndt.c:116-147); rendered by the sampled path, parity is statistical */
 };
 
 /* One light (reference `light`, scene.h:36-49).  pos/dir are offsets, in doubles, into
@@ -72,9 +72,10 @@ typedef struct ndt_flat_light {
     int32_t type;
     int32_t pos_off;
     int32_t dir_off;
-    int32_t _pad;
+    int32_t area_off;           /* ABI 3, DISK / RECT: u1[dims] then v1[dims] (scene_prepare_light, scene.c:182-195), else -1 */
     double  red, green, blue;
     double  angle;              /* spot cone half-angle, degrees (ndt.c:204) */
+    double  radius;             /* ABI 3, DISK / RECT: the sample is pos + x*radius*u1 + y*radius*v1 (ndt.c:126-141) */
 } ndt_flat_light;
 
 /* One object (reference `object`, object.h:23-74) with its API-level parameters as the scene

@@ -46,12 +46,29 @@ struct SceneDesc {
     int off_params;    // per-type parameter records
     int trace_words;   // everything above: what the trace kernel stages in LDS
     int off_mat;       // 8 words per object: rgb, reflect rgb, refract index, transparent
-    int off_lights;    // per light: {int type,0}, r,g,b, angle, pos[N], dir[N]
+    int off_lights;    // per light: {int type,0}, r,g,b, angle, pos[N], dir[N], radius, u1[N], v1[N]
     int off_cam;       // pos[N], img_orig[N], dir_x[N], dir_y[N], focal, ambient[3], background[4]
     int total_words;
     int mask_words;    // 64-bit words of visit mask per ray (kd-tree.c:600)
     int kd_depth;      // deepest leaf of the kd-tree (root = 1): the traversal stack never holds more entries
 };
+
+// ------------------------------------------------------------------ random streams
+// The stochastic paths (-n > 1: jitter + lens; area lights) draw from counter-based streams: every
+// number is a hash of (stream key, draw index), so nothing depends on scheduling, sharding or the
+// order in which a bounce was compacted.  A primary sample's key comes from its image pixel and
+// sample number; a child ray's key from its parent's key and its kind.
+NDT_DEV unsigned long long ndt_rng_mix(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull;                 // splitmix64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+NDT_DEV double ndt_rng_uniform(unsigned long long key, unsigned int k)
+{
+    return (double)(ndt_rng_mix(key + k) >> 11) * (1.0 / 9007199254740992.0);      // [0, 1)
+}
 
 // ------------------------------------------------------------------ vectNd.h
 

@@ -77,6 +77,7 @@ struct ndt_hip_ctx {
     double aperture_radius = 0.0;   // camera.h:46 of the uploaded scene
     int cam_type = 0;
     bool have_eyes = false, have_local_axes = false;
+    bool has_area_lights = false;   // LIGHT_DISK / LIGHT_RECT: every render is stochastic (ndt.c:116-147)
     SceneDesc sd{};
     std::vector<double> blob;
     double *d_blob = nullptr;
@@ -800,13 +801,15 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     }
     sd.off_lights = b.words();
     int n_shadow_lights = 0;
+    bool has_area_lights = false;
     for (int i = 0; i < fs->n_lights; ++i) {
         const ndt_flat_light &l = fs->lights[i];
         double zero[NDT_MAX_DIMS] = { 0 };
-        if (l.type == NDT_LIGHT_DISK || l.type == NDT_LIGHT_RECT)
-            return fail(NDT_E_UNSUPPORTED, "light %d: area lights sample drand48 per ray (ndt.c:116-147); not on the device path", i);
         if (l.type < 0 || l.type > NDT_LIGHT_RECT) return fail(NDT_E_INVALID, "light %d: type %d", i, l.type);
-        const bool want_pos = l.type == NDT_LIGHT_POINT || l.type == NDT_LIGHT_SPOT;
+        const bool area = l.type == NDT_LIGHT_DISK || l.type == NDT_LIGHT_RECT;
+        if (area && !vec_ok(fs, l.area_off, 2)) return fail(NDT_E_INVALID, "light %d: area lights need u1 / v1 (scene.c:182-195) in the flat scene", i);
+        if (area) has_area_lights = true;
+        const bool want_pos = l.type == NDT_LIGHT_POINT || l.type == NDT_LIGHT_SPOT || area;
         const bool want_dir = l.type == NDT_LIGHT_DIRECTIONAL || l.type == NDT_LIGHT_SPOT;
         if (want_pos && !vec_ok(fs, l.pos_off, 1)) return fail(NDT_E_INVALID, "light %d: position missing", i);
         if (want_dir && !vec_ok(fs, l.dir_off, 1)) return fail(NDT_E_INVALID, "light %d: direction missing", i);
@@ -816,7 +819,11 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         b.push(l.angle);
         b.push_vec(want_pos ? fs->vecs + l.pos_off : zero, n);
         b.push_vec(want_dir ? fs->vecs + l.dir_off : zero, n);
+        b.push(area ? l.radius : 0.0);
+        b.push_vec(area ? fs->vecs + l.area_off : zero, n);         // u1
+        b.push_vec(area ? fs->vecs + l.area_off + n : zero, n);     // v1
     }
+    ctx->has_area_lights = has_area_lights;
     if (!vec_ok(fs, fs->cam_pos_off, 1) || !vec_ok(fs, fs->cam_img_orig_off, 1) || !vec_ok(fs, fs->cam_dir_x_off, 1) ||
         !vec_ok(fs, fs->cam_dir_y_off, 1))
         return fail(NDT_E_INVALID, "camera vectors out of range");
@@ -926,6 +933,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.depth, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.rng_key, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return rc;
@@ -1615,22 +1623,15 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
 // (tests compare against the oracle, which follows the reference's stream exactly).
 // Round r renders sample r of every pixel that is still sampling, through the pipeline in list mode.
 
-__device__ __forceinline__ unsigned long long ns_mix(unsigned long long z)
+// the random stream of sample `round` of image pixel `pixel`
+__device__ __forceinline__ unsigned long long ns_sample_key(unsigned long long pixel, unsigned int round)
 {
-    z += 0x9e3779b97f4a7c15ull;                 // splitmix64
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ double ns_uniform(unsigned long long pixel, unsigned int round, unsigned int k)
-{
-    const unsigned long long h = ns_mix(ns_mix(pixel * 0x100000001b3ull + round) + k);
-    return (double)(h >> 11) * (1.0 / 9007199254740992.0);         // [0, 1)
+    return ndt_rng_mix(pixel * 0x100000001b3ull + round);
 }
 
 // sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
 __global__ void k_ns_samples(const int *active, int n_active, int width, int row_begin, int row_step, unsigned int round,
-                             double aperture, double *samples)
+                             double aperture, int jitter, double *samples, unsigned long long *keys)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_active) return;
@@ -1638,14 +1639,19 @@ __global__ void k_ns_samples(const int *active, int n_active, int width, int row
     const int l = pix / width, i = pix % width;
     const int j = row_begin + l * row_step;
     const unsigned long long id = (unsigned long long)j * (unsigned long long)width + (unsigned long long)i;
-    const double dx = ns_uniform(id, round, 0), dy = ns_uniform(id, round, 1);
-    double ax, ay;
-    unsigned int k = 2;
-    do {        // reject samples outside the unit disk
-        ax = 2 * ns_uniform(id, round, k) - 1.0;
-        ay = 2 * ns_uniform(id, round, k + 1) - 1.0;
-        k += 2;
-    } while (ax * ax + ay * ay > 1.0 && k < 64);
+    const unsigned long long key = ns_sample_key(id, round);
+    keys[a] = key;
+    double dx = 0.0, dy = 0.0, ax = 0.0, ay = 0.0;
+    if (jitter) {       // -n > 1 only (ndt.c:505, 528); with -n 1 the area lights are all that is random
+        dx = ndt_rng_uniform(key, 1000);
+        dy = ndt_rng_uniform(key, 1001);
+        unsigned int k = 1002;
+        do {        // reject samples outside the unit disk
+            ax = 2 * ndt_rng_uniform(key, k) - 1.0;
+            ay = 2 * ndt_rng_uniform(key, k + 1) - 1.0;
+            k += 2;
+        } while (ax * ax + ay * ay > 1.0 && k < 1064);
+    }
     double *q = samples + 4ll * a;
     q[0] = i + dx;          // x = orig_x + dx/width
     q[1] = j - dy;          // y = orig_y + dy/height, and y grows upwards
@@ -1712,10 +1718,12 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
     AaBuffers buf;
     int rc;
     double *acc = nullptr, *samples = nullptr, *colours = nullptr;
+    unsigned long long *keys = nullptr;
     int *list[2] = { nullptr, nullptr }, *taken = nullptr, *counter = nullptr;
     if ((rc = buf.get(&acc, (size_t)n_pixels * 5))) return rc;
     if ((rc = buf.get(&samples, (size_t)n_pixels * 4))) return rc;
     if ((rc = buf.get(&colours, (size_t)n_pixels * 4))) return rc;
+    if ((rc = buf.get(&keys, (size_t)n_pixels + 64))) return rc;
     if ((rc = buf.get(&list[0], (size_t)n_pixels))) return rc;
     if ((rc = buf.get(&list[1], (size_t)n_pixels))) return rc;
     if ((rc = buf.get(&taken, (size_t)n_pixels))) return rc;
@@ -1726,7 +1734,7 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
     for (unsigned int round = 0; n_active > 0 && round < 10000; ++round) {
         const unsigned g_act = (unsigned)((n_active + 255) / 256);
         hipLaunchKernelGGL(k_ns_samples, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, W, p->row_begin, p->row_step, round,
-                           ctx->aperture_radius, samples);
+                           ctx->aperture_radius, p->samples > 1 ? 1 : 0, samples, keys);
         RenderGeom gs{};
         gs.samples = samples;
         gs.n_samples = n_active;
@@ -1742,6 +1750,7 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
         gs.eye = 1;
         gs.lens = 1;
         gs.raw_samples = 1;
+        gs.sample_keys = keys;
         ndt_render_stats st{};
         if ((rc = render_pass(ctx, gs, p->profile != 0, colours, st))) return rc;
         add_stats(total, st);
@@ -1776,8 +1785,9 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (!ctx || !p || !d_rgba) return fail(NDT_E_INVALID, "NULL argument");
     if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
     if (p->samples < 1) return fail(NDT_E_INVALID, "samples=%d", p->samples);
-    if (p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
-        return fail(NDT_E_UNSUPPORTED, "samples > 1 is implemented for the mono planar camera without recursive anti-aliasing or a depth map");
+    const bool stochastic = p->samples > 1 || ctx->has_area_lights;
+    if (stochastic && (p->recursive_aa || p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
+        return fail(NDT_E_UNSUPPORTED, "samples > 1 and area lights are implemented for the mono planar camera without recursive anti-aliasing or a depth map");
     if (p->samples > 1 && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
         return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
@@ -1813,7 +1823,7 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     // the reference's switch: -a with depth >= 0 and diff < 256 resamples, otherwise the first pass is copied (ndt.c:1040)
     if (p->recursive_aa) {
         rc = render_antialiased(ctx, p, d_rgba, st);
-    } else if (p->samples > 1) {
+    } else if (stochastic) {
         rc = render_sampled(ctx, p, d_rgba, st);
     } else {
         RenderGeom rg{};

@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
     store_soa<N>(ws.ray_v, ws.cap, g, look);
     ws.frac[g] = 1.0;
     ws.depth_left[g] = rg.max_depth;
+    if (rg.samples && rg.sample_keys) ws.rng_key[g] = rg.sample_keys[g];
 }
 
 // ------------------------------------------------------------------ trace
@@ -487,7 +488,7 @@ struct LightRec {
     int type;
     double red, green, blue, angle;
 };
-NDT_DEV int light_word(const SceneDesc &sd, int i) { return sd.off_lights + i * (5 + 2 * N); }
+NDT_DEV int light_word(const SceneDesc &sd, int i) { return sd.off_lights + i * (6 + 4 * N); }
 
 // Per light: everything apply_lights does before its trace_kd call (ndt.c:113-208, 230-236).
 // Returns false when the light is skipped for this hit (ambient, wrong side, outside the cone).
@@ -496,13 +497,34 @@ struct ShadowSetup {
 };
 NDT_DEV bool light_setup(const double *blob, const SceneDesc &sd, int li, const double (&src)[N], const double (&hit)[N],
                          const double (&hit_normal)[N], int &type, double (&lgt_pos)[N], double (&rev_light)[N],
-                         double (&light_vec)[N], double (&shadow_o)[N], ShadowSetup &ss)
+                         double (&light_vec)[N], double (&shadow_o)[N], ShadowSetup &ss, unsigned long long key = 0ull)
 {
     const int w = light_word(sd, li);
     type = blob_int(blob, w, 0);
-    if (type != NDT_LIGHT_POINT_ && type != NDT_LIGHT_DIRECTIONAL_ && type != NDT_LIGHT_SPOT_) return false;
     double ldir[N], rev_view[N];
     blob_vec<N>(blob, w + 5, lgt_pos);
+    if (type == 4 || type == 5) {
+        // LIGHT_DISK / LIGHT_RECT: a random point of the light, then a point light (ndt.c:116-147).
+        // shade_emit and shade_finish call this with the same node key and so see the same point.
+        const unsigned long long lk = ndt_rng_mix(key ^ (0x51ed270b27b4f3cfull * (unsigned long long)(li + 1)));
+        double x, y;
+        unsigned int k = 0;
+        do {
+            x = 2 * ndt_rng_uniform(lk, k) - 1.0;
+            y = 2 * ndt_rng_uniform(lk, k + 1) - 1.0;
+            k += 2;
+        } while (type == 4 && x * x + y * y > 1.0 && k < 64);
+        const double radius = blob[w + 5 + 2 * N];
+        double ax[N], temp[N];
+        blob_vec<N>(blob, w + 6 + 2 * N, ax);
+        v_scale<N>(ax, x * radius, temp);
+        v_add<N>(lgt_pos, temp, lgt_pos);
+        blob_vec<N>(blob, w + 6 + 3 * N, ax);
+        v_scale<N>(ax, y * radius, temp);
+        v_add<N>(lgt_pos, temp, lgt_pos);
+        type = NDT_LIGHT_POINT_;
+    }
+    if (type != NDT_LIGHT_POINT_ && type != NDT_LIGHT_DIRECTIONAL_ && type != NDT_LIGHT_SPOT_) return false;
     blob_vec<N>(blob, w + 5 + N, ldir);
     if (type == NDT_LIGHT_DIRECTIONAL_)
         v_scale<N>(ldir, -1, rev_light);                    // ndt.c:157
@@ -582,13 +604,14 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     // waits for a single atomic round trip however many lights there are.
     const int lane = __lane_id();
     unsigned long long fire = 0ull;
+    const unsigned long long node_key = (rg.sample_keys && in_range) ? ws.rng_key[g] : 0ull;    // stochastic renders only
     NDT_SEC(0);
     if (shaded) {
         for (int li = 0; li < sd.n_lights; ++li) {
             int type;
             double lgt_pos[N], rev_light[N], light_vec[N], so[N];
             ShadowSetup ss;
-            if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss)) fire |= 1ull << li;
+            if (light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, node_key)) fire |= 1ull << li;
         }
     }
     NDT_SEC(1);
@@ -668,6 +691,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
         ws.child_refr[c] = -1;
         ws.count[c] = 0;
         ws.sh_mask[c] = 0ull;
+        if (rg.sample_keys) ws.rng_key[c] = ndt_rng_mix(node_key ^ 0x1ull);
         ws.child_refl[g] = (int)c;
     }
     if (want_refr) {
@@ -680,6 +704,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
         ws.child_refr[c] = -1;
         ws.count[c] = 0;
         ws.sh_mask[c] = 0ull;
+        if (rg.sample_keys) ws.rng_key[c] = ndt_rng_mix(node_key ^ 0x2ull);
         ws.child_refr[g] = (int)c;
     }
     NDT_SEC(3);
@@ -694,7 +719,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             int type;
             double lgt_pos[N], rev_light[N], light_vec[N], so[N];
             ShadowSetup ss;
-            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, node_key);
             const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
             const long long slot = (long long)seg * lr.seg_stride + idx;
             ws.sh_idx[(long long)seg * ws.cap + g] = idx;
@@ -772,7 +797,8 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
             int type;
             double lgt_pos[N], rev_light[N], light_vec[N], so[N], light_hit_normal[N];
             ShadowSetup ss;
-            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss);
+            light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss,
+                        rg.sample_keys ? ws.rng_key[g] : 0ull);
             const int sobj = ws.sobj[slot];
             const int sprim = ws.sprim[slot];
             ++n_shadow;

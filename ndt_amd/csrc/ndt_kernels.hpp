@@ -33,6 +33,7 @@ struct Workspace {
     unsigned long long *sh_mask;// [cap]      lights that fired a shadow ray
     int *count;                 // [cap]      trace_kd calls in this node's subtree
     double *depth;              // [cap]      primaries of a depth-map render: 1/distance of the hit, 0 on a miss
+    unsigned long long *rng_key;// [cap]      stochastic renders: the node's random stream (ndt_device.hpp)
     // shadow queue of the current bounce
     long long sh_cap;
     double *so, *sv;            // [N][sh_cap]
@@ -70,6 +71,7 @@ struct RenderGeom {
     int n_samples;
     int lens;                   // list mode: records are (i, j, lx, ly): the eye is moved by lx*localX + ly*localY (ndt.c:538-541)
     int raw_samples;            // list mode: one colour per sample as traced (-n > 1), no replay of the samples=1 loop
+    const unsigned long long *sample_keys;  // list mode, stochastic renders: the random stream of every sample
     int stereo;                 // ndt_stereo_mode: 1 side by side, 2 over/under split the image between the eyes (ndt.c:590-612)
     int eye;                    // 0 left, 1 centre, 2 right: the eye when stereo does not split the image (anaglyph renders twice)
     int want_depth;             // record 1/distance of the primary hits (depth maps, ndt.c:362-373)

@@ -10,7 +10,7 @@ import ctypes as C
 import gzip
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MIN_DIMS, MAX_DIMS = 3, 8
 
 OBJ_TYPES = ["sphere", "hplane", "hdisk", "cylinder", "hcylinder", "orthotope", "hcube", "hfacet", "facet"]
@@ -21,8 +21,9 @@ NDT_OK, NDT_E_INVALID, NDT_E_UNSUPPORTED, NDT_E_DEVICE, NDT_E_NOMEM, NDT_E_STATE
 
 
 class FlatLight(C.Structure):
-    _fields_ = [("type", C.c_int32), ("pos_off", C.c_int32), ("dir_off", C.c_int32), ("_pad", C.c_int32),
-                ("red", C.c_double), ("green", C.c_double), ("blue", C.c_double), ("angle", C.c_double)]
+    _fields_ = [("type", C.c_int32), ("pos_off", C.c_int32), ("dir_off", C.c_int32), ("area_off", C.c_int32),
+                ("red", C.c_double), ("green", C.c_double), ("blue", C.c_double), ("angle", C.c_double),
+                ("radius", C.c_double)]
 
 
 class FlatObject(C.Structure):
@@ -155,6 +156,7 @@ class FlatScene:
             s = self.lights_a[i]
             s.type, s.pos_off, s.dir_off = l["type"], l["pos_off"], l["dir_off"]
             s.red, s.green, s.blue, s.angle = l["red"], l["green"], l["blue"], l["angle"]
+            s.area_off, s.radius = l.get("area_off", -1), l.get("radius", 0.0)
         self.objects_a = (FlatObject * max(1, len(self.objects)))()
         for i, o in enumerate(self.objects):
             s = self.objects_a[i]
@@ -263,6 +265,12 @@ def load_scene(path):
         dr = [_hx(t) for t in need("ldir")[1:]]
         l["pos_off"] = fs.add_vec(pos) if has_pos else -1
         l["dir_off"] = fs.add_vec(dr) if has_dir else -1
+        l["area_off"], l["radius"] = -1, 0.0
+        if len(tok) > 17 and int(tok[17]):
+            # area light (ndtscene 2 files written since ABI 3): radius, then the prepared basis u1, v1
+            l["radius"] = _hx(tok[15])
+            l["area_off"] = fs.add_vec([_hx(t) for t in need("lu1")[1:]])
+            fs.add_vec([_hx(t) for t in need("lv1")[1:]])
         fs.lights.append(l)
     tok = need("objects")
     n_objects, fs.n_items = int(tok[1]), int(tok[3])

@@ -176,6 +176,15 @@ int ndt_flatten_scene(scene *scn, ndt_flat_builder *fb, char *err, int err_len)
             fl->angle = l->angle;
             fl->pos_off = (l->pos.v && l->pos.n == dims) ? push_vec(fb, &l->pos, dims) : -1;
             fl->dir_off = (l->dir.v && l->dir.n == dims) ? push_vec(fb, &l->dir, dims) : -1;
+            fl->area_off = -1;
+            fl->radius = 0.0;
+            if (l->type == LIGHT_DISK || l->type == LIGHT_RECT) {
+                /* the basis the first shading evaluation would derive (ndt.c:123-125, scene.c:182-195) */
+                if (!l->prepared) scene_prepare_light(l);
+                fl->area_off = push_vec(fb, &l->u1, dims);
+                push_vec(fb, &l->v1, dims);
+                fl->radius = l->radius;
+            }
         }
         fs->vecs = fb->vecs;         fs->n_vecs = fb->n_vecs;
         fs->sizes = fb->sizes;       fs->n_sizes = fb->n_sizes;
@@ -217,7 +226,9 @@ int ndt_write_ndtscene(const ndt_flat_scene *fs, const char *name, const char *p
     const int d = fs->dims;
     /* version 2 adds the camera2 block; plain pinhole cameras are written as version 1, the form
      * the fixtures flattened from the compiled reference have (oracle/ref_shim.c:dump_scene) */
-    const int v2 = (fs->cam_type != 0 || fs->cam_aperture_radius != 0.0 || getenv("NDT_NDTSCENE_V2")) &&
+    int area_lights = 0;
+    for (int i = 0; i < fs->n_lights; ++i) area_lights |= fs->lights[i].area_off >= 0;
+    const int v2 = (fs->cam_type != 0 || fs->cam_aperture_radius != 0.0 || area_lights || getenv("NDT_NDTSCENE_V2")) &&
                    fs->cam_left_eye_off >= 0 && fs->cam_right_eye_off >= 0 && fs->cam_local_x_off >= 0 &&
                    fs->cam_local_y_off >= 0 && fs->cam_local_z_off >= 0;
     fprintf(f, "ndtscene %d\nname %s\ndims %d\n", v2 ? 2 : 1, name, d);
@@ -239,10 +250,16 @@ int ndt_write_ndtscene(const ndt_flat_scene *fs, const char *name, const char *p
     fprintf(f, "lights %d\n", fs->n_lights);
     for (int i = 0; i < fs->n_lights; ++i) {
         const ndt_flat_light *l = &fs->lights[i];
-        fprintf(f, "light %d type %d color %a %a %a angle %a has_pos %d has_dir %d\n", i, l->type, l->red, l->green, l->blue,
+        fprintf(f, "light %d type %d color %a %a %a angle %a has_pos %d has_dir %d", i, l->type, l->red, l->green, l->blue,
                 l->angle, l->pos_off >= 0, l->dir_off >= 0);
+        if (v2) fprintf(f, " radius %a has_area %d", l->radius, l->area_off >= 0);
+        fprintf(f, "\n");
         put(f, "lpos", l->pos_off >= 0 ? fs->vecs + l->pos_off : NULL, d);
         put(f, "ldir", l->dir_off >= 0 ? fs->vecs + l->dir_off : NULL, d);
+        if (v2 && l->area_off >= 0) {
+            put(f, "lu1", fs->vecs + l->area_off, d);
+            put(f, "lv1", fs->vecs + l->area_off + d, d);
+        }
     }
     fprintf(f, "objects %d items %d\n", fs->n_objects, fs->n_items);
     for (int i = 0; i < fs->n_objects; ++i) {

@@ -999,6 +999,7 @@ typedef struct {
     ray_counts cnt;
     int specular;
     int samples;            /* `-n`: > 1 = jittered samples + lens sampling with drand48 (ndt.c:505-542) */
+    int stochastic;         /* samples > 1 or area lights: every pass of the adaptive loop is a different ray tree */
     double pix_w, pix_h;    /* 1/width, 1/height of the image being rendered (ndt.c:482-483) */
 } tctx;
 
@@ -1035,9 +1036,24 @@ static void apply_lights(tctx *T, int obj_idx, const double *src, const double *
             clr.b += hit_b * L->blue;
             continue;
         }
-        if (lgt_type != NDT_LIGHT_POINT && lgt_type != NDT_LIGHT_DIRECTIONAL && lgt_type != NDT_LIGHT_SPOT)
-            continue;       /* area lights need drand48 (ndt.c:116-147): out of scope, rejected at entry */
         if (Lpos) v_copy(lgt_pos, Lpos, n);
+        if (lgt_type == NDT_LIGHT_DISK || lgt_type == NDT_LIGHT_RECT) {
+            /* a random point of the areal light (ndt.c:116-147), from the global drand48 stream; from
+             * here on the sample is a point light */
+            const double *u1 = fs->vecs + L->area_off, *v1 = u1 + n;
+            double x, y, temp[ND];
+            do {
+                x = 2 * drand48() - 1.0;
+                y = 2 * drand48() - 1.0;
+            } while (lgt_type == NDT_LIGHT_DISK && x * x + y * y > 1.0);
+            v_scale(u1, x * L->radius, temp, n);
+            v_add(lgt_pos, temp, lgt_pos, n);
+            v_scale(v1, y * L->radius, temp, n);
+            v_add(lgt_pos, temp, lgt_pos, n);
+            lgt_type = NDT_LIGHT_POINT;
+        }
+        if (lgt_type != NDT_LIGHT_POINT && lgt_type != NDT_LIGHT_DIRECTIONAL && lgt_type != NDT_LIGHT_SPOT)
+            continue;
 
         if (lgt_type == NDT_LIGHT_POINT || lgt_type == NDT_LIGHT_SPOT)
             v_sub(lgt_pos, hit, rev_light, n);
@@ -1294,7 +1310,7 @@ static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_opt
     int n = S->n;
     double look[ND], pixel[ND], virtCam[ND];
     const int samples = T->samples > 1 ? T->samples : 1;
-    if (samples > 1) literal = 1;              /* every sample is a different ray */
+    if (T->stochastic) literal = 1;            /* every sample is a different ray tree */
     const double orig_x = x, orig_y = y;
     int min_samples = samples;
     int max_samples = 10000;
@@ -1385,6 +1401,7 @@ typedef struct {
     int n1;
     long long resampled, aa_samples;
     double *depth;          /* depth map (1/distance of the primary hit), or NULL */
+    int stochastic;
 } job;
 
 /* render_pixel (ndt.c:578-653, MONO) + get_pixel_color: the sample at image position (i, j), both in
@@ -1394,7 +1411,7 @@ static void one_eye(job *J, tctx *T, double x, double y, pix *clr, int mode, dou
     int k = 0;
     ray_counts b = T->cnt;
     get_pixel_color_m(T, x, y, clr, J->p->max_optic_depth, J->literal, &k, mode, depth);
-    if (T->samples > 1) k = 1;      /* every sample was a ray of its own */
+    if (T->stochastic) k = 1;       /* every sample was a ray tree of its own */
     J->unique.primary += (T->cnt.primary - b.primary) / k;
     J->unique.secondary += (T->cnt.secondary - b.secondary) / k;
     J->unique.shadow += (T->cnt.shadow - b.shadow) / k;
@@ -1440,6 +1457,7 @@ static void tctx_open(tctx *T, job *J)
     memset(&T->cnt, 0, sizeof(T->cnt));
     T->specular = J->p->specular;
     T->samples = J->p->samples;
+    T->stochastic = J->stochastic;
     T->pix_w = 1.0 / (J->p->width + (J->p->recursive_aa ? 1 : 0));
     T->pix_h = 1.0 / (J->p->height + (J->p->recursive_aa ? 1 : 0));
 }
@@ -1589,8 +1607,8 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     if (p && p->stereo != NDT_STEREO_MONO && (fs->cam_left_eye_off < 0 || fs->cam_right_eye_off < 0)) return NDT_E_INVALID;
     for (int i = 0; i < fs->n_lights; ++i) {
         const ndt_flat_light *L = &fs->lights[i];
-        if (L->type == NDT_LIGHT_DISK || L->type == NDT_LIGHT_RECT)
-            return NDT_E_UNSUPPORTED;
+        if ((L->type == NDT_LIGHT_DISK || L->type == NDT_LIGHT_RECT) && (L->area_off < 0 || L->pos_off < 0))
+            return NDT_E_INVALID;
         if ((L->type == NDT_LIGHT_POINT || L->type == NDT_LIGHT_SPOT) && L->pos_off < 0) return NDT_E_INVALID;
         if ((L->type == NDT_LIGHT_DIRECTIONAL || L->type == NDT_LIGHT_SPOT) && L->dir_off < 0) return NDT_E_INVALID;
     }
@@ -1648,7 +1666,10 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
     rc = prepare_scene(fs, &S);
     if (rc != NDT_OK) return rc;
     if (threads < 1) threads = 1;
-    if (p->samples > 1) {
+    int stochastic = p->samples > 1;
+    for (int i = 0; i < fs->n_lights; ++i)
+        if (fs->lights[i].type == NDT_LIGHT_DISK || fs->lights[i].type == NDT_LIGHT_RECT) stochastic = 1;
+    if (stochastic) {
         /* the random numbers come from one global stream in pixel order: one thread, starting where the
          * reference run that made the fixture stood (ndt_oracle_set_seed48) */
         unsigned short x0[3] = { g_seed48[0], g_seed48[1], g_seed48[2] };
@@ -1663,6 +1684,7 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
         jobs[i].S = &S; jobs[i].p = p; jobs[i].rgba = rgba; jobs[i].thr = i; jobs[i].threads = threads;
         jobs[i].literal = flags & 1;
         jobs[i].depth = depth;
+        jobs[i].stochastic = stochastic;
     }
     ray_counts cnt1 = { 0, 0, 0 };
     double *pass1 = NULL;

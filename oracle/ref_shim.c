@@ -201,10 +201,19 @@ static void dump_scene(const char *path, scene *scn)
         light *l = scn->lights[i];
         int has_pos = (l->pos.v != NULL && l->pos.n == dims);
         int has_dir = (l->dir.v != NULL && l->dir.n == dims);
-        fprintf(f, "light %d type %d color %a %a %a angle %a has_pos %d has_dir %d\n", i, (int)l->type,
+        int has_area = (l->type == LIGHT_DISK || l->type == LIGHT_RECT);
+        fprintf(f, "light %d type %d color %a %a %a angle %a has_pos %d has_dir %d", i, (int)l->type,
                 l->red, l->green, l->blue, l->angle, has_pos, has_dir);
+        if (scene_v2) fprintf(f, " radius %a has_area %d", l->radius, has_area);
+        fprintf(f, "\n");
         put_vec(f, "lpos", has_pos ? &l->pos : NULL, dims);
         put_vec(f, "ldir", has_dir ? &l->dir : NULL, dims);
+        if (scene_v2 && has_area) {
+            /* the basis apply_lights derives at the first shading evaluation (ndt.c:123-125, scene.c:182-195) */
+            if (!l->prepared) scene_prepare_light(l);
+            put_vec(f, "lu1", &l->u1, dims);
+            put_vec(f, "lv1", &l->v1, dims);
+        }
     }
     fprintf(f, "objects %d items %d\n", n_fobjs, n_items);
     for (int i = 0; i < n_fobjs; ++i) {

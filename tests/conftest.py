@@ -110,5 +110,5 @@ KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c
 FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
-SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof"]       # -n samples > 1 (meta: "samples")
+SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3"]   # -n samples > 1 and / or area lights
 VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

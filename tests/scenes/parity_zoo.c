@@ -102,6 +102,32 @@ int scene_setup(scene *scn, int dims, int frame, int frames, char *config)
     set_axis(&l->dir, dims, -0.4, -1.0, -0.7, -0.2);
     l->red = 0.35; l->green = 0.35; l->blue = 0.45;
 
+    /* config "area": a disk and a rectangle light (ndt.c:116-147), bases deliberately not orthogonal
+     * (scene_prepare_light orthogonalises them, scene.c:182-195) */
+    if (config && strstr(config, "area")) {
+        scene_alloc_light(scn, &l);
+        l->type = LIGHT_DISK;
+        vectNd_calloc(&l->pos, dims);
+        vectNd_calloc(&l->u, dims);
+        vectNd_calloc(&l->v, dims);
+        set_axis(&l->pos, dims, 4.0, 22.0, -9.0, 1.0);
+        set_axis(&l->u, dims, 1.0, 0.1, 0.3, 0.0);
+        set_axis(&l->v, dims, 0.2, 0.0, 1.0, 0.4);
+        l->radius = 2.5;
+        l->red = 180; l->green = 150; l->blue = 120;
+
+        scene_alloc_light(scn, &l);
+        l->type = LIGHT_RECT;
+        vectNd_calloc(&l->pos, dims);
+        vectNd_calloc(&l->u, dims);
+        vectNd_calloc(&l->v, dims);
+        set_axis(&l->pos, dims, -14.0, 18.0, 10.0, -2.0);
+        set_axis(&l->u, dims, 0.0, 0.2, 1.0, 0.1);
+        set_axis(&l->v, dims, 1.0, 0.5, 0.0, 0.0);
+        l->radius = 3.0;
+        l->red = 90; l->green = 140; l->blue = 200;
+    }
+
     object *o;
     /* floor: hplane with a non-unit normal */
     o = add(scn, dims, "hplane", 0.7, 0.7, 0.65, mirror ? 0.97 : 0.35);

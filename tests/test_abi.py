@@ -29,13 +29,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     # natural alignment of the C structs in include/ndt_hip.h
-    assert C.sizeof(fsmod.FlatLight) == 16 + 4 * 8
+    assert C.sizeof(fsmod.FlatLight) == 16 + 5 * 8
     assert C.sizeof(fsmod.FlatObject) == 14 * 4 + 8 * 8
     assert C.sizeof(fsmod.FlatKdNode) == 32
     assert C.sizeof(fsmod.RenderParams) == 16 * 4
     assert C.sizeof(fsmod.RenderStats) == 4 * 8 + 2 * 4 + 3 * 8 + 2 * 8
     # the library and the binding agree on the ABI revision the flat scene carries
-    assert nh.load_library().ndt_hip_abi_version() == fsmod.ABI_VERSION == 2
+    assert nh.load_library().ndt_hip_abi_version() == fsmod.ABI_VERSION == 3
 
 
 def test_shard_rows_helper_agrees_with_library():

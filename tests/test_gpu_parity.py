@@ -251,3 +251,24 @@ def test_jittered_samples_statistically_match_the_oracle(gpu, oracle, name):
     assert np.array_equal(again, first)
     part, _ = gpu.render(g.width, g.height, g.depth, samples=8, row_begin=1, row_step=2)
     assert np.array_equal(part, first[1::2])
+
+
+def test_area_lights_make_even_one_sample_stochastic(gpu, oracle):
+    """LIGHT_DISK / LIGHT_RECT (ndt.c:116-147): a random point of the light per shading evaluation, so
+    with -n 1 the adaptive loop's repeats differ and it keeps sampling until the running mean settles.
+    Device and oracle (= the reference's stream) agree statistically and take the same number of samples."""
+    g = golden("al_zoo4d")
+    gpu.upload_scene(g.scene)
+    want, so = oracle.render(g.scene, g.width, g.height, g.depth, samples=1, seed48=g.meta["seed48"])
+    out, st = gpu.render(g.width, g.height, g.depth, samples=1)
+    n = g.width * g.height
+    assert abs(st.rays_primary / n - so.rays_primary / n) < 0.15 * so.rays_primary / n
+    assert st.rays_primary > 2 * n                      # more than one pass of the loop everywhere
+    assert np.abs(out[..., :3] - want[..., :3]).mean() < 0.02
+    assert abs(out[..., :3].mean() - want[..., :3].mean()) < 0.01
+    again, _ = gpu.render(g.width, g.height, g.depth, samples=1)
+    assert np.array_equal(out, again)
+    # the modes that need the deterministic path say so
+    from ndt_amd.hip import NdtHipError
+    with pytest.raises(NdtHipError):
+        gpu.render(g.width, g.height, g.depth, aa=(20, 2))
