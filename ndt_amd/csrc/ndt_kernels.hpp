@@ -129,7 +129,9 @@ extern "C" const NdtKernelTable *ndt_kernel_table_7();
 extern "C" const NdtKernelTable *ndt_kernel_table_8();
 
 #define NDT_TRACE_BLOCK 256
+#ifndef NDT_TRACE_MAX_BLOCK
 #define NDT_TRACE_MAX_BLOCK 768
+#endif
 #define NDT_QUEUE_SLOTS 512                 /* trace launches per render call that get a work queue */
 #define NDT_QUEUE_SHARDS 8                  /* queue heads per launch (one per XCD-sized group of workgroups) */
 #define NDT_QUEUE_STRIDE 16                 /* ints between heads: one 64-byte line each */
