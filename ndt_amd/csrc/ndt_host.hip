@@ -1234,6 +1234,9 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         }
         long long upper = rg.n_primary;         // node count of the bounce
         std::vector<long long> level_nodes;
+        static const bool fuse_shade = !(getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR")));
+        int pending_finish = -1;                // bounce whose lighting has not been launched yet
+        long long pending_upper = 0;
         for (int b = 0; b < n_levels; ++b) {
             if (queue_slot + 1 > NDT_QUEUE_SLOTS || b + 1 > NDT_MAX_LEVELS)
                 return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
@@ -1253,8 +1256,18 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                 }
             }
             level_nodes.push_back(upper);
-            // hit points, shadow rays of this bounce, and the rays of the next bounce
-            kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+            // hit points, shadow rays of this bounce, and the rays of the next bounce -- in the same launch as the
+            // lighting of the previous bounce, which is waiting for the shadow answers the last trace launch produced
+            if (pending_finish >= 0 && fuse_shade) {
+                kt->shade_pair(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper, upper);
+                pending_finish = -1;
+            } else {
+                if (pending_finish >= 0) {
+                    kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper);
+                    pending_finish = -1;
+                }
+                kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+            }
             hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
             long long next_upper = 2 * upper;           // each node spawns at most two
             if (next_upper > ws.cap) next_upper = ws.cap;
@@ -1273,8 +1286,10 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                 tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = b + 1;
                 if ((rc = traced(tj, "shadow " + std::to_string(b) + " + closest " + std::to_string(b + 1)))) return rc;
             }
-            kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+            pending_finish = b;
+            pending_upper = upper;
         }
+        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper);
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
             for (int b = n_run; b-- > 0;) {

@@ -851,6 +851,21 @@ __global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, Sce
     if (base < lr.count) shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
 }
 
+// lighting of bounce `level` in the first n_finish workgroups, shading of bounce level+1 in the rest
+__global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
+                                                       unsigned n_finish)
+{
+    if (blockIdx.x < n_finish) {
+        const LevelRange lr = ws.levels[level];
+        const long long base = (long long)blockIdx.x * blockDim.x;
+        if (base < lr.count) shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+    } else {
+        const LevelRange lr = ws.levels[level + 1];
+        const long long base = (long long)(blockIdx.x - n_finish) * blockDim.x;
+        if (base < lr.count) shade_emit_node(blob, sd, ws, rg, lr, level + 1, base + threadIdx.x);
+    }
+}
+
 // ------------------------------------------------------------------ hit points for the trace_kd batch API
 
 __global__ void __launch_bounds__(256) k_hitpoints(const double *blob, SceneDesc sd, const double *o, const double *v,
@@ -891,6 +906,13 @@ static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd,
     if (upper <= 0) return;
     hipLaunchKernelGGL(k_shade_finish, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level);
 }
+static void launch_shade_pair(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
+                              long long upper_finish, long long upper_emit)
+{
+    const unsigned nf = upper_finish > 0 ? shade_grid(upper_finish) : 0, ne = upper_emit > 0 ? shade_grid(upper_emit) : 0;
+    if (nf + ne == 0) return;
+    hipLaunchKernelGGL(k_shade_pair, dim3(nf + ne), dim3(256), 0, s, blob, sd, ws, rg, level, nf);
+}
 static void launch_hitpoints(hipStream_t s, const double *blob, SceneDesc sd, const double *o, const double *v,
                              long long stride, const int *prim, double *hit, double *nrm, long long count)
 {
@@ -904,6 +926,6 @@ extern "C" const NdtKernelTable *NDT_CAT(ndt_kernel_table_, NDT_DIMS)()
 {
     using namespace NDT_CAT(ndt_d, NDT_DIMS);
     static const NdtKernelTable table = { NDT_DIMS, launch_primary, launch_trace, launch_shade_emit, launch_shade_finish,
-                                          launch_hitpoints };
+                                          launch_shade_pair, launch_hitpoints };
     return &table;
 }

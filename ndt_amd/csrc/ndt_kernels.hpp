@@ -117,6 +117,10 @@ struct NdtKernelTable {
     // `upper` bounds the bounce's node count (sizes the grid); the range itself is ws.levels[level]
     void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
     void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
+    // shade_finish(level) and shade_emit(level + 1) in one launch: they touch different nodes, and both are
+    // short latency-bound kernels for the small deep bounces
+    void (*shade_pair)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper_finish,
+                       long long upper_emit);
     void (*hitpoints)(hipStream_t, const double *blob, SceneDesc, const double *o, const double *v, long long stride,
                       const int *prim, double *hit, double *nrm, long long count);
 };
