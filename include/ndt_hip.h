@@ -193,7 +193,9 @@ typedef struct ndt_render_stats {
     int64_t node_capacity;      /* ray-tree nodes the workspace holds */
     /* ABI 2 */
     int64_t pixels_resampled;   /* recursive AA: pixels that were subdivided (the reference's "pixels resampled") */
-    int64_t aa_samples;         /* recursive AA: extra get_pixel_color samples rendered by the second pass */
+    int64_t aa_samples;         /* recursive AA: extra get_pixel_color samples rendered by the second pass;
+                                 * stochastic renders (-n > 1, area lights): samples the adaptive loop consumed
+                                 * (rays_* then also count the samples rendered ahead and dropped) */
 } ndt_render_stats;
 
 /* stereo_mode (ndt.c:46-48).  SIDE_SIDE / OVER_UNDER put the left-eye image in the left / top half and

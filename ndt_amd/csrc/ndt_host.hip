@@ -1645,12 +1645,14 @@ __device__ __forceinline__ unsigned long long ns_sample_key(unsigned long long p
 }
 
 // sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
-__global__ void k_ns_samples(const int *active, int n_active, int width, int row_begin, int row_step, unsigned int round,
+// (`per` consecutive samples per pixel in one pass: sample a*per + r is the pixel's sample number round + r)
+__global__ void k_ns_samples(const int *active, int n_active, int per, int width, int row_begin, int row_step, unsigned int round0,
                              double aperture, int jitter, double *samples, unsigned long long *keys)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_active) return;
-    const int pix = active[a];
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (long long)n_active * per) return;
+    const int pix = active[a / per];
+    const unsigned int round = round0 + (unsigned int)(a % per);
     const int l = pix / width, i = pix % width;
     const int j = row_begin + l * row_step;
     const unsigned long long id = (unsigned long long)j * (unsigned long long)width + (unsigned long long)i;
@@ -1675,27 +1677,36 @@ __global__ void k_ns_samples(const int *active, int n_active, int width, int row
 }
 
 // get_pixel_color's loop body after the sample has been traced (ndt.c:553-567), and its continuation test
-__global__ void k_ns_accumulate(const int *active, int n_active, const double *colours, unsigned int round, int min_samples,
-                                double *acc, int *next, int *next_count)
+// A pass may have rendered `per` samples ahead for every pixel; they are consumed one by one exactly as the
+// loop would, and the ones after the loop's exit are dropped (they were speculation: fewer, fuller passes).
+__global__ void k_ns_accumulate(const int *active, int n_active, int per, const double *colours, unsigned int round0, int min_samples,
+                                double *acc, int *taken, int *next, int *next_count)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_active) return;
     const int pix = active[a];
-    const double *l = colours + 4ll * a;
     double *t = acc + 5ll * pix;            // t_clr rgba + clr_diff
-    const int i = (int)round;
     double clr_diff = t[4];
-    if (i > 1) {
-        const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
-        const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
-        const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
-        const double gb = (dg > db) ? dg : db;
-        clr_diff = (dr > gb) ? dr : gb;
+    bool go_on = true;
+    int used = 0;
+    for (int r = 0; r < per && go_on; ++r) {
+        const double *l = colours + 4ll * ((long long)a * per + r);
+        const int i = (int)round0 + r;
+        if (i > 1) {
+            const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+            const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+            const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+            const double gb = (dg > db) ? dg : db;
+            clr_diff = (dr > gb) ? dr : gb;
+        }
+        t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
+        ++used;
+        const int done = i + 1;
+        go_on = done < min_samples || (done < 10000 && clr_diff > 1.0 / 256.0);
     }
-    t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
     t[4] = clr_diff;
-    const int done = i + 1;
-    if (done < min_samples || (done < 10000 && clr_diff > 1.0 / 256.0)) next[atomicAdd(next_count, 1)] = pix;
+    taken[pix] += used;
+    if (go_on) next[atomicAdd(next_count, 1)] = pix;
 }
 
 __global__ void k_ns_init(double *acc, int *active, int *taken, long long n_pixels)
@@ -1709,18 +1720,17 @@ __global__ void k_ns_init(double *acc, int *active, int *taken, long long n_pixe
     taken[i] = 0;
 }
 
-__global__ void k_ns_count(const int *active, int n_active, int *taken)
-{
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < n_active) taken[active[a]] += 1;
-}
-
-__global__ void k_ns_finish(const double *acc, const int *taken, double *rgba, long long n_pixels)
+__global__ void k_ns_finish(const double *acc, const int *taken, double *rgba, long long n_pixels, unsigned long long *used_total)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    const int n = taken[i] > 0 ? taken[i] : 1;
-    for (int c = 0; c < 4; ++c) rgba[4 * i + c] = acc[5 * i + c] / n;
+    unsigned long long used = 0;
+    if (i < n_pixels) {
+        const int n = taken[i] > 0 ? taken[i] : 1;
+        for (int c = 0; c < 4; ++c) rgba[4 * i + c] = acc[5 * i + c] / n;
+        used = (unsigned long long)taken[i];
+    }
+    for (int d = 32; d > 0; d >>= 1) used += __shfl_down(used, d, 64);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(used_total, used);
 }
 
 static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total)
@@ -1736,9 +1746,6 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
     unsigned long long *keys = nullptr;
     int *list[2] = { nullptr, nullptr }, *taken = nullptr, *counter = nullptr;
     if ((rc = buf.get(&acc, (size_t)n_pixels * 5))) return rc;
-    if ((rc = buf.get(&samples, (size_t)n_pixels * 4))) return rc;
-    if ((rc = buf.get(&colours, (size_t)n_pixels * 4))) return rc;
-    if ((rc = buf.get(&keys, (size_t)n_pixels + 64))) return rc;
     if ((rc = buf.get(&list[0], (size_t)n_pixels))) return rc;
     if ((rc = buf.get(&list[1], (size_t)n_pixels))) return rc;
     if ((rc = buf.get(&taken, (size_t)n_pixels))) return rc;
@@ -1746,15 +1753,34 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
     const unsigned g_all = (unsigned)((n_pixels + 255) / 256);
     hipLaunchKernelGGL(k_ns_init, dim3(g_all), dim3(256), 0, s, acc, list[0], taken, n_pixels);
     int n_active = (int)n_pixels;
-    for (unsigned int round = 0; n_active > 0 && round < 10000; ++round) {
+    // samples per pixel and pass: the first `samples` are certain to be needed; after that the loop may stop at
+    // any sample, so passes speculate further ahead the fewer pixels are left (about 4 M primaries per pass)
+    const long long per_pass = 4ll << 20;
+    size_t cap_samples = 0;
+    int flip = 0;
+    for (unsigned int round = 0; n_active > 0 && round < 10000;) {
+        long long per = round < (unsigned int)p->samples ? (long long)p->samples - round : per_pass / n_active;
+        if (per > per_pass / n_active) per = per_pass / n_active;
+        // ... but never more than have been taken already: the waste stays below a factor of two
+        if (round >= (unsigned int)p->samples && per > (long long)(round < 2 ? 1 : round)) per = round < 2 ? 1 : round;
+        if (per < 1) per = 1;
+        if (per > 64) per = 64;
+        if (round + per > 10000) per = 10000 - round;
+        const long long n_s = (long long)n_active * per;
+        if ((size_t)n_s > cap_samples) {
+            cap_samples = (size_t)n_s;
+            if ((rc = buf.get(&samples, cap_samples * 4))) return rc;
+            if ((rc = buf.get(&colours, cap_samples * 4))) return rc;
+            if ((rc = buf.get(&keys, cap_samples + 64))) return rc;
+        }
         const unsigned g_act = (unsigned)((n_active + 255) / 256);
-        hipLaunchKernelGGL(k_ns_samples, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, W, p->row_begin, p->row_step, round,
-                           ctx->aperture_radius, p->samples > 1 ? 1 : 0, samples, keys);
+        hipLaunchKernelGGL(k_ns_samples, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, list[flip], n_active, (int)per, W,
+                           p->row_begin, p->row_step, round, ctx->aperture_radius, p->samples > 1 ? 1 : 0, samples, keys);
         RenderGeom gs{};
         gs.samples = samples;
-        gs.n_samples = n_active;
-        gs.n_primary = (n_active + 63) & ~63;
-        gs.width = n_active;
+        gs.n_samples = (int)n_s;
+        gs.n_primary = (int)((n_s + 63) & ~63LL);
+        gs.width = (int)n_s;
         gs.rows = 1;
         gs.max_depth = p->max_optic_depth;
         gs.specular = p->specular ? 1 : 0;
@@ -1770,15 +1796,21 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
         if ((rc = render_pass(ctx, gs, p->profile != 0, colours, st))) return rc;
         add_stats(total, st);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_ns_count, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, taken);
-        hipLaunchKernelGGL(k_ns_accumulate, dim3(g_act), dim3(256), 0, s, list[round & 1], n_active, colours, round, p->samples, acc,
-                           list[(round + 1) & 1], counter);
+        hipLaunchKernelGGL(k_ns_accumulate, dim3(g_act), dim3(256), 0, s, list[flip], n_active, (int)per, colours, round, p->samples,
+                           acc, taken, list[flip ^ 1], counter);
         HIP_TRY(hipMemcpyAsync(&n_active, counter, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        flip ^= 1;
+        round += (unsigned int)per;
     }
-    hipLaunchKernelGGL(k_ns_finish, dim3(g_all), dim3(256), 0, s, acc, taken, (double *)d_rgba, n_pixels);
+    unsigned long long *used_total = nullptr, used_host = 0;
+    if ((rc = buf.get(&used_total, 1))) return rc;
+    HIP_TRY(hipMemsetAsync(used_total, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_ns_finish, dim3(g_all), dim3(256), 0, s, acc, taken, (double *)d_rgba, n_pixels, used_total);
+    HIP_TRY(hipMemcpyAsync(&used_host, used_total, sizeof(used_host), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    total.aa_samples = (long long)used_host;       // samples the adaptive loop consumed (the rays_* counts include the speculation)
     return NDT_OK;
 }
 

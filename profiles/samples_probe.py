@@ -19,7 +19,7 @@ for S in (2, 8, 32, 128):
     out, st = gpu.render(g.width, g.height, g.depth, samples=S)
     print("%s %dx%d -n %d: mean |device - oracle| %.5f, image means %.5f / %.5f, samples per pixel device %.1f oracle %.1f" % (
         g.name, g.width, g.height, S, np.abs(out[..., :3] - want[..., :3]).mean(), out[..., :3].mean(), want[..., :3].mean(),
-        st.rays_primary / (g.width * g.height), so.rays_primary / (g.width * g.height)))
+        st.aa_samples / (g.width * g.height), so.rays_primary / (g.width * g.height)))
 w, h = 1920, 1080
 buf = torch.empty((h, w, 4), dtype=torch.float64, device="cuda")
 for S in (4, 16):
@@ -30,4 +30,4 @@ for S in (4, 16):
     torch.cuda.synchronize()
     d = st.as_dict()
     print("%s 1920x1080 -n %d: %.1f ms, %d rays traced, %.1f samples per pixel" % (
-        g.name, S, 1e3 * (time.perf_counter() - t0), d["rays_primary"] + d["rays_secondary"] + d["rays_shadow"], d["rays_primary"] / (w * h)))
+        g.name, S, 1e3 * (time.perf_counter() - t0), d["rays_primary"] + d["rays_secondary"] + d["rays_shadow"], d["aa_samples"] / (w * h)))
