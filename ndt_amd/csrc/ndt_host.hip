@@ -87,6 +87,7 @@ struct ndt_hip_ctx {
     // workspace
     Workspace ws{};
     std::vector<void *> ws_allocs;
+    std::vector<std::pair<void *, size_t>> pool;    // scratch of the multi-pass renderers (AaBuffers)
     long long ws_dims = 0;
     long long ws_slab_words = 0;
     int ws_nseg = 0;
@@ -177,6 +178,8 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
+    for (auto &slot : ctx->pool)
+        if (slot.first) (void)hipFree(slot.first);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -1496,16 +1499,32 @@ __global__ void k_aa_resolve(const AaTask *tasks, int n_tasks, int leaf, AaTask 
     for (int c = 0; c < 4; ++c) dst[c] = res[c];
 }
 
+// Scratch buffers of the multi-pass renderers (anti-aliasing levels, sample rounds, anaglyph eyes).  The
+// requests of a frame come in the same order every frame, so the k-th request reuses the k-th
+// allocation of the context's pool (grown when too small) instead of a hipMalloc / hipFree pair, each of
+// which synchronises the device.
 struct AaBuffers {
-    std::vector<void *> allocs;
-    ~AaBuffers() { for (void *q : allocs) (void)hipFree(q); }
+    ndt_hip_ctx *ctx;
+    size_t next = 0;
+    explicit AaBuffers(ndt_hip_ctx *c) : ctx(c) {}
     template <typename T> int get(T **ptr, size_t count)
     {
-        void *q = nullptr;
-        hipError_t e = hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T));
-        if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
-        allocs.push_back(q);
-        *ptr = (T *)q;
+        const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
+        if (next == ctx->pool.size()) ctx->pool.push_back({ nullptr, 0 });
+        auto &slot = ctx->pool[next++];
+        if (slot.second < bytes) {
+            if (slot.first) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(slot.first);
+                slot = { nullptr, 0 };
+            }
+            const size_t want = bytes + bytes / 4;          // some head room: frame-to-frame counts vary
+            void *q = nullptr;
+            hipError_t e = hipMalloc(&q, want);
+            if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", want, hipGetErrorString(e));
+            slot = { q, want };
+        }
+        *ptr = (T *)slot.first;
         return NDT_OK;
     }
 };
@@ -1529,7 +1548,7 @@ static int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void
     const bool prof = p->profile != 0;
     const int W = p->width, H = p->height;
     const int rows = ndt_hip_shard_rows(H, p->row_begin, p->row_step);
-    AaBuffers buf;
+    AaBuffers buf(ctx);
     int rc;
     // ---- first pass: the corner rows this shard touches, (W+1) wide (ndt.c:919-976)
     RenderGeom g1{};
@@ -1740,7 +1759,7 @@ static int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_
     const int rows = ndt_hip_shard_rows(H, p->row_begin, p->row_step);
     const long long n_pixels = (long long)rows * W;
     if (n_pixels > 0x3fffffffLL) return fail(NDT_E_UNSUPPORTED, "image too large for one call");
-    AaBuffers buf;
+    AaBuffers buf(ctx);
     int rc;
     double *acc = nullptr, *samples = nullptr, *colours = nullptr;
     unsigned long long *keys = nullptr;
@@ -1893,7 +1912,7 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
         rg.eye = 1;
         if (p->stereo == NDT_STEREO_ANAGLYPH) {
             // two full renders, one per eye (ndt.c:636-647); the depth map is the left eye's
-            AaBuffers buf;
+            AaBuffers buf(ctx);
             double *left = nullptr, *right = nullptr;
             if ((rc = buf.get(&left, (size_t)n_pixels * 4))) return rc;
             if ((rc = buf.get(&right, (size_t)n_pixels * 4))) return rc;
