@@ -20,6 +20,8 @@ static double now_s(void)
     return tv.tv_sec + 1e-6 * tv.tv_usec;
 }
 
+static int write_png(const char *path, const double *rgba, int w, int h);
+
 static int write_ppm(const char *path, const double *rgba, int w, int h)
 {
     FILE *f = fopen(path, "wb");
@@ -42,7 +44,7 @@ static int write_ppm(const char *path, const double *rgba, int w, int h)
 
 /* ---- one frame: flatten, upload, render, save (what follows scene_setup in the reference's frame loop) */
 static struct {
-    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth, samples;
+    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth, samples, png;
     const char *raw_path;
 } job_opts;
 
@@ -64,8 +66,13 @@ static int render_frame(scene *scn, int i)
     snprintf(dir, sizeof(dir), "images/%s", scn->name); mkdir(dir, 0700);
     snprintf(dir, sizeof(dir), "images/%s/%id", scn->name, job_opts.dims); mkdir(dir, 0700);
     snprintf(dir, sizeof(dir), "images/%s/%id/%ix%i", scn->name, job_opts.dims, width, height); mkdir(dir, 0700);
-    snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn->name, width, height, i);
-    write_ppm(path, rgba, width, height);
+    if (job_opts.png) {
+        snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.png", dir, scn->name, width, height, i);
+        write_png(path, rgba, width, height);
+    } else {
+        snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn->name, width, height, i);
+        write_ppm(path, rgba, width, height);
+    }
     printf("\tsaved %s\n", path);
     if (depth_map) {
         /* dbl_image_normalize (image.c:1025-1065) stretches the map to 0..1 before it is saved (ndt.c:1010-1016) */
@@ -167,17 +174,105 @@ static int yaml_scene_setup(scene *scn, int dimensions, int frame, int frames, c
     return 0;
 }
 
+/* ---- PNG, 8-bit RGBA like the reference's writer (image.c:563-660: PNG_COLOR_TYPE_RGB_ALPHA, pixel_d2c on every
+ * channel), without libpng: the zlib stream inside IDAT uses stored (uncompressed) deflate blocks */
+static unsigned int crc_table[256];
+static void crc_init(void)
+{
+    for (unsigned int n = 0; n < 256; ++n) {
+        unsigned int c = n;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        crc_table[n] = c;
+    }
+}
+static unsigned int crc_update(unsigned int c, const unsigned char *buf, size_t len)
+{
+    for (size_t i = 0; i < len; ++i) c = crc_table[(c ^ buf[i]) & 0xff] ^ (c >> 8);
+    return c;
+}
+static void put_be32(unsigned char *p, unsigned int v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+static void png_chunk(FILE *f, const char *type, const unsigned char *data, size_t len)
+{
+    unsigned char hdr[8];
+    put_be32(hdr, (unsigned int)len);
+    memcpy(hdr + 4, type, 4);
+    fwrite(hdr, 1, 8, f);
+    if (len) fwrite(data, 1, len, f);
+    unsigned int c = crc_update(0xffffffffu, hdr + 4, 4);
+    c = crc_update(c, data, len) ^ 0xffffffffu;
+    unsigned char tail[4];
+    put_be32(tail, c);
+    fwrite(tail, 1, 4, f);
+}
+
+static int write_png(const char *path, const double *rgba, int w, int h)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    crc_init();
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    fwrite(sig, 1, 8, f);
+    unsigned char ihdr[13];
+    put_be32(ihdr, (unsigned int)w);
+    put_be32(ihdr + 4, (unsigned int)h);
+    ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;     /* 8 bit, RGBA, no interlace */
+    png_chunk(f, "IHDR", ihdr, 13);
+    /* raw image: one filter byte (0 = none) + 4 bytes per pixel, per row */
+    const size_t row = 1 + (size_t)w * 4, raw_len = row * (size_t)h;
+    unsigned char *raw = (unsigned char *)malloc(raw_len);
+    for (int j = 0; j < h; ++j) {
+        unsigned char *q = raw + (size_t)j * row;
+        *q++ = 0;
+        for (int i = 0; i < w; ++i)
+            for (int c = 0; c < 4; ++c) {
+                double d = rgba[((size_t)j * w + i) * 4 + c];
+                double m = (1.0 < d) ? 1.0 : d;                 /* pixel_d2c, image.h:36-39 */
+                m = (0.0 > m) ? 0.0 : m;
+                *q++ = (unsigned char)(sqrt(m) * 255);
+            }
+    }
+    /* zlib: header, stored blocks of at most 65535 bytes, adler32 */
+    const size_t n_blocks = (raw_len + 65534) / 65535;
+    const size_t z_len = 2 + raw_len + 5 * (n_blocks ? n_blocks : 1) + 4;
+    unsigned char *z = (unsigned char *)malloc(z_len), *zp = z;
+    *zp++ = 0x78; *zp++ = 0x01;
+    unsigned int a = 1, b = 0;
+    size_t off = 0;
+    do {
+        size_t n = raw_len - off > 65535 ? 65535 : raw_len - off;
+        *zp++ = (off + n == raw_len) ? 1 : 0;
+        *zp++ = n & 0xff; *zp++ = (n >> 8) & 0xff; *zp++ = ~n & 0xff; *zp++ = (~n >> 8) & 0xff;
+        memcpy(zp, raw + off, n);
+        for (size_t i = 0; i < n; ++i) {        /* adler32; the modulo can wait 5552 bytes, but this is not the hot path */
+            a = (a + raw[off + i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        zp += n;
+        off += n;
+    } while (off < raw_len);
+    put_be32(zp, (b << 16) | a);
+    zp += 4;
+    png_chunk(f, "IDAT", z, (size_t)(zp - z));
+    png_chunk(f, "IEND", NULL, 0);
+    free(z);
+    free(raw);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
     int depth = 128, threads = 1;
     int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
     int jobs = 1;           /* -j: frames in flight */
+    int png = 0;            /* --png: 8-bit RGBA PNG like the reference's default IMAGE_FORMAT (image.h:56-64) instead of PPM */
     int samples = 1;        /* -n (ndt.c:1574-1577) */
     int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
-                                        { "raw", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
+                                        { "raw", required_argument, NULL, 1001 }, { "png", no_argument, NULL, 1002 },
+                                        { NULL, 0, NULL, 0 } };
     int ch;
     while ((ch = getopt_long(argc, argv, "a:d:r:f:j:l:m:3:n:ps:t:u:o:zh", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
@@ -224,9 +319,10 @@ int main(int argc, char **argv)
         case 'o': break;    /* object plugins are built in */
         case 1000: dump_path = optarg; break;
         case 1001: raw_path = optarg; break;
+        case 1002: png = 1; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-a diff,depth] [-n samples] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64]\n", argv[0]);
+                            "          [-a diff,depth] [-n samples] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64] [--png]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -255,7 +351,7 @@ int main(int argc, char **argv)
 
     job_opts.dims = dims; job_opts.width = width; job_opts.height = height; job_opts.depth = depth; job_opts.threads = threads;
     job_opts.aa_diff = aa_diff; job_opts.aa_depth = aa_depth; job_opts.stereo = stereo; job_opts.specular = specular;
-    job_opts.want_depth = want_depth; job_opts.raw_path = raw_path; job_opts.samples = samples;
+    job_opts.want_depth = want_depth; job_opts.raw_path = raw_path; job_opts.samples = samples; job_opts.png = png;
     /* -j K: K frames in flight.  The scene program runs on this thread, frame after frame (it may
      * keep state between frames, ndt.c:1818-1825); everything after it -- bounding spheres, kd-tree,
      * upload, render, image files -- happens on K worker threads, each with its own GPU context.

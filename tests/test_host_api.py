@@ -165,3 +165,39 @@ def test_frames_in_flight_produce_the_same_images(driver, tmp_path):
         outs.append([p.read_bytes() for p in files])
     assert outs[0] == outs[1]
     assert len(set(outs[0])) == 6       # an animation: every frame differs
+
+
+def _read_png_rgba(path):
+    """Minimal PNG reader for what ndt_hip --png writes (8-bit RGBA, filter 0 on every row)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            w, h, bits, colour = struct.unpack(">IIBB", body[:10])
+            assert (bits, colour) == (8, 6)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
+def test_png_at_1080p_is_the_references_image_byte_for_byte(driver, tmp_path):
+    """BASELINE config 3 end to end: the reference's scene binary -> this host -> the GPU -> an 8-bit RGBA PNG
+    whose every byte is the one the compiled reference's image holds (pixel_d2c of its framebuffer)."""
+    g = golden("c3_random4d_1080p")
+    cmd = [driver, "-s", os.path.join(REF_BIN, "random.so"), "-d", "4", "-f", "0", "-r", "1920x1080", "-l", str(g.depth), "--png"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    files = list((tmp_path / "images").rglob("*.png"))
+    assert len(files) == 1
+    assert np.array_equal(_read_png_rgba(str(files[0])), g.data["rgba8"])
