@@ -200,7 +200,9 @@ typedef struct ndt_render_stats {
 
 /* stereo_mode (ndt.c:46-48).  SIDE_SIDE / OVER_UNDER put the left-eye image in the left / top half and
  * the right-eye image in the other (each squeezed to half size), ANAGLYPH mixes the luminance of the
- * two eyes into red and blue (ndt.c:590-650).  HIDEF_3D (frame-packed 1080p) is not implemented. */
+ * two eyes into red and blue (ndt.c:590-650).  HIDEF packs 1080 lines of the left eye, 45 black lines and 1080
+ * lines of the right eye (ndt.c:614-631; `-m h` sets 1920x2205); the reference leaves the alpha of the black
+ * lines unset, this library writes 1. */
 enum ndt_stereo_mode {
     NDT_STEREO_MONO = 0, NDT_STEREO_SIDE_SIDE = 1, NDT_STEREO_OVER_UNDER = 2, NDT_STEREO_ANAGLYPH = 3, NDT_STEREO_HIDEF = 4
 };

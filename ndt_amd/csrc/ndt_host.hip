@@ -1857,8 +1857,7 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (p->samples > 1 && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
         return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
-    if (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)
-        return fail(NDT_E_UNSUPPORTED, "stereo mode %d (mono, side by side, over/under and anaglyph are implemented)", p->stereo);
+    if (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_HIDEF) return fail(NDT_E_UNSUPPORTED, "stereo mode %d", p->stereo);
     if (p->stereo != NDT_STEREO_MONO && !ctx->have_eyes) return fail(NDT_E_INVALID, "stereo needs leftEye / rightEye (camera.h:60-61) in the flat scene");
     for (int k = 0; k < 4; ++k)
         if (p->reserved[k] != 0) return fail(NDT_E_INVALID, "reserved render parameter set");
@@ -1929,6 +1928,13 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
             rc = NDT_OK;
         } else {
             rg.stereo = p->stereo;
+            if (p->stereo == NDT_STEREO_HIDEF) {
+                // frame packing (ndt.c:614-631, 927-928): the aspect is width/1080 and the 45 blank lines between the
+                // eyes stay black (the reference leaves their alpha unset; 1 here)
+                rg.aspect_h = 1080;
+                hipLaunchKernelGGL(k_fill_black, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, (double *)d_rgba, n_pixels);
+                if (d_depth) HIP_TRY(hipMemsetAsync(d_depth, 0, (size_t)n_pixels * sizeof(double), s));
+            }
             rc = render_pass(ctx, rg, p->profile != 0, d_rgba, st, d_depth);
         }
     }

@@ -109,8 +109,22 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
         if (jp < rg.img_h / 2) { jp = jp / 0.5; eye = 0; }
         else { jp = (jp - rg.img_h / 2) / 0.5; eye = 2; }
     }
+    double y_div = (double)rg.img_h;
+    if (rg.stereo == 4) {           // HIDEF_3D frame packing (ndt.c:614-631): 1080 lines left eye, 45 blank, 1080 right eye
+        y_div = 1080.0;
+        if (jp < 1080) {
+            eye = 0;
+        } else if (jp > 1080 + 45) {
+            jp = jp - (1080 + 45);
+            eye = 2;
+        } else {
+            ws.depth_left[g] = 0;   // blank line: black, written by the host's fill
+            ws.hit_obj[g] = -1;
+            return;
+        }
+    }
     const double x = ip / (double)rg.img_w - 0.5;               // ndt.c:632
-    const double y = -(jp / (double)rg.img_h - 0.5);            // ndt.c:633
+    const double y = -(jp / y_div - 0.5);                       // ndt.c:633 (629 for HIDEF_3D)
     double pos[N], pixel[N], temp[N], look[N], cam[N];
     blob_vec<N>(blob, sd.off_cam, pos);
     const double focal = blob[sd.off_cam + 4 * N];

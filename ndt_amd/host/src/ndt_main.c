@@ -306,7 +306,7 @@ int main(int argc, char **argv)
             case 'S': case 's': stereo = 1; printf("stereo = SIDE_SIDE_3D\n"); break;
             case 'O': case 'o': stereo = 2; printf("stereo = OVER_UNDER_3D\n"); break;
             case 'A': case 'a': stereo = 3; printf("stereo = ANAGLYPH_3D\n"); break;
-            case 'H': case 'h': fprintf(stderr, "HIDEF_3D is not implemented\n"); return 1;
+            case 'H': case 'h': stereo = 4; width = 1920; height = 2205; printf("stereo = HIDEF_3D\n"); break;     /* ndt.c:1557-1565 */
             default: stereo = 0; printf("stereo = MONO\n"); break;
             }
             break;

@@ -1432,6 +1432,19 @@ static void render_pixel_d(job *J, tctx *T, int width, int height, double i, dou
     }
     double x = ip / (double)width - 0.5;
     double y = -(jp / (double)height - 0.5);
+    if (stereo == NDT_STEREO_HIDEF) {               /* frame packing, ndt.c:614-631: left eye, 45 blank lines, right eye */
+        if (j < 1080) {
+            mode = CAM_LEFT;
+        } else if (j > (1080 + 45)) {
+            jp = j - (1080 + 45);
+            mode = CAM_RIGHT;
+        } else {
+            clr->r = clr->g = clr->b = 0;
+            clr->a = 1.0;           /* the reference leaves alpha unset here */
+            return;
+        }
+        y = -(jp / 1080.0 - 0.5);
+    }
     if (stereo == NDT_STEREO_ANAGLYPH) {            /* ndt.c:636-647 */
         pix left, right;
         one_eye(J, T, x, y, &left, CAM_LEFT, depth);
@@ -1617,7 +1630,7 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     /* samples > 1: jitter + lens sampling from drand48 (ndt.c:505-542); not combined with the other modes here */
     if (p && p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO)) return NDT_E_UNSUPPORTED;
     if (p && p->samples > 1 && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
-    if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_ANAGLYPH)) return NDT_E_UNSUPPORTED;
+    if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_HIDEF)) return NDT_E_UNSUPPORTED;
     if (p && p->stereo != NDT_STEREO_MONO && p->recursive_aa) return NDT_E_UNSUPPORTED;
     /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
     if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0) return NDT_E_UNSUPPORTED;
@@ -1676,7 +1689,8 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
         seed48(x0);
         threads = 1;
     }
-    v_scale(S.cam_dir_x, p->width / (double)p->height, S.cam_dir_x, S.n);      /* ndt.c:926 */
+    if (p->stereo == NDT_STEREO_HIDEF) v_scale(S.cam_dir_x, p->width / (double)1080, S.cam_dir_x, S.n);      /* ndt.c:928 */
+    else v_scale(S.cam_dir_x, p->width / (double)p->height, S.cam_dir_x, S.n);                                /* ndt.c:926 */
     job *jobs = (job *)calloc((size_t)threads, sizeof(job));
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);

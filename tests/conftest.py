@@ -93,6 +93,16 @@ class Golden:
         self.width, self.height, self.depth = self.meta["width"], self.meta["height"], self.meta["depth"]
 
 
+def comparable(fb, stereo):
+    """What of a framebuffer the reference defines: with HIDEF_3D frame packing the 45 blank lines between the
+    eyes get r = g = b = 0 and an alpha that is never set (ndt.c:624-627); those alphas are masked out."""
+    if stereo != 4:
+        return fb
+    out = np.array(fb, copy=True)
+    out[1080:1080 + 46, :, 3] = 0.0
+    return out
+
+
 _golden_cache = {}
 
 
@@ -111,4 +121,4 @@ FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
 SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3"]   # -n samples > 1 and / or area lights
-VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]
+VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "st_zoo3d_hidef", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

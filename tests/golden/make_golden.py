@@ -77,6 +77,9 @@ CASES = {
                         share_scene="st_zoo4d_sbs"),
     "st_zoo3d_anaglyph": dict(scene="parity_zoo", dims=3, res=(48, 36), depth=6, fb=True, kat=0, stereo=3, v2=True,
                               depth_map=True),
+    # HIDEF_3D frame packing: 1080 lines left eye, 45 blank, 1080 right eye (ndt.c:614-631); narrow to stay small
+    "st_zoo3d_hidef": dict(scene="parity_zoo", dims=3, res=(24, 2205), depth=4, fb=True, kat=0, stereo=4, v2=True,
+                           share_scene="st_zoo3d_anaglyph"),
     "vr_zoo4d": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, v2=True, config="vr",
                      depth_map=True),
     "pano_zoo5d_sbs": dict(scene="parity_zoo", dims=5, res=(64, 32), depth=5, fb=True, kat=0, v2=True, config="pano",

@@ -9,7 +9,7 @@ may differ in the last ulps, hence TOL_TIGHT is what we actually expect and TOL_
 import numpy as np
 import pytest
 
-from conftest import golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
+from conftest import comparable, golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -202,7 +202,7 @@ def test_stereo_vr_pano_and_depth_maps_vs_reference(gpu, name):
         assert np.abs(dm - g.data["depth"]).max() < TOL_TIGHT
     else:
         out, st = gpu.render(g.width, g.height, g.depth, stereo=stereo)
-    diff = np.abs(out - g.data["fb"])
+    diff = np.abs(comparable(out, stereo) - comparable(g.data["fb"], stereo))
     assert diff.max() < (TOL_TIGHT if g.scene.cam_type == 0 else 1e-7), "max abs diff %g" % diff.max()
     assert st.rays_ref_equiv == g.meta["rays_total"]
 
