@@ -46,6 +46,10 @@ WORKLOADS = {
     "random4d": ("c3_random4d", 4, "random", 4, 2),
     "balls4d": ("c2_balls4d", 128, "balls", 4, 1),
     "hypercube3d": ("c1_hypercube3d", 128, "hypercube", 3, 0),
+    # configs[4]: the 6-D .. 8-D sweep (728 / 2186 / 6560 objects: scene in global memory, visit masks in a slab)
+    "hypercube6d": ("c5_hypercube6d", 128, "hypercube", 6, 4),
+    "hypercube7d": ("c5_hypercube7d", 128, "hypercube", 7, 4),
+    "hypercube8d": ("c5_hypercube8d", 128, "hypercube", 8, 4),
 }
 
 
