@@ -236,7 +236,17 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
     const double *blob = gblob;
     if (LDS) {
-        for (int i = threadIdx.x; i < sd.trace_words; i += blockDim.x) lds_blob[i] = gblob[i];
+        // 16 bytes per lane and four loads in flight per lane: the copy is a few round trips to L2, not one per word
+        const int pairs = sd.trace_words >> 1;
+        const ndt_v2d *src2 = reinterpret_cast<const ndt_v2d *>(gblob);
+        ndt_v2d *dst2 = reinterpret_cast<ndt_v2d *>(lds_blob);
+        int i = threadIdx.x;
+        for (; i + 3 * (int)blockDim.x < pairs; i += 4 * blockDim.x) {
+            const ndt_v2d a = src2[i], b = src2[i + blockDim.x], c = src2[i + 2 * blockDim.x], d = src2[i + 3 * blockDim.x];
+            dst2[i] = a; dst2[i + blockDim.x] = b; dst2[i + 2 * blockDim.x] = c; dst2[i + 3 * blockDim.x] = d;
+        }
+        for (; i < pairs; i += blockDim.x) dst2[i] = src2[i];
+        if ((sd.trace_words & 1) && threadIdx.x == 0) lds_blob[sd.trace_words - 1] = gblob[sd.trace_words - 1];
         __syncthreads();
         blob = lds_blob;
     }
@@ -298,21 +308,32 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     // tail gets longer, and the launch slower.)
     int shard_try = 0;
     const int home = blockIdx.x % NDT_QUEUE_SHARDS;
+    unsigned live_shards = (1u << NDT_QUEUE_SHARDS) - 1u;       // shards that may still hold batches (bit = shard index)
     while (true) {
         long long b = -1;           // logical batch
         while (shard_try < NDT_QUEUE_SHARDS) {
             const int sh_i = (home + shard_try) % NDT_QUEUE_SHARDS;
             const long long n_here = (n_batches - sh_i + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
             int k = 0;
-            if (n_here > 0) {
+            const bool may = n_here > 0 && ((live_shards >> sh_i) & 1u);
+            if (may) {
                 if (lane == 0) k = atomicAdd(job.queue + sh_i * NDT_QUEUE_STRIDE, 1);
                 k = __shfl(k, 0, 64);
             }
-            if (n_here > 0 && k < n_here) {
+            if (may && k < n_here) {
                 b = (long long)k * NDT_QUEUE_SHARDS + sh_i;
                 break;
             }
             ++shard_try;       // this shard is drained for good
+            if (shard_try == 1) {
+                // home shard empty: look at all the other heads in ONE round trip (lane i reads head i) before
+                // trying them one atomic at a time -- at the end of a launch they are all drained
+                int head = 0x7fffffff;
+                if (lane < NDT_QUEUE_SHARDS)
+                    head = __hip_atomic_load(job.queue + lane * NDT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long mine = (n_batches - lane + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+                live_shards = (unsigned)__ballot(lane < NDT_QUEUE_SHARDS && (long long)head < mine);
+            }
         }
         if (b < 0) break;
         long long g;
@@ -456,7 +477,12 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
         // Traversal stack in LDS when it fits beside the scene: one workgroup of 768 lanes per CU (the scene is
         // staged once instead of three times), 12 bytes per level and lane.  NDT_TRACE_LSTACK=0 switches back
         // to the scratch stack with NDT_TRACE_BLOCK-sized workgroups (also what deeper trees / bigger scenes get).
-        static const int lstack_block = env_int("NDT_TRACE_LSTACK", NDT_TRACE_MAX_BLOCK);
+        static const int lstack_full = env_int("NDT_TRACE_LSTACK", NDT_TRACE_MAX_BLOCK);
+        static const int small_launch = env_int("NDT_TRACE_SMALL", 4096);     // batches below which a launch counts as small
+        // A launch with fewer batches than the chip has wavefront slots is pure latency: give every wavefront a
+        // SIMD of its own (256-lane workgroups spread over the CUs) instead of packing twelve into one CU.
+        int lstack_block = lstack_full;
+        if (lstack_full >= 256 && upper / job.batch < small_launch) lstack_block = 256;
         const size_t lds_stack = ((size_t)((sd.trace_words + 1) & ~1) * 8) + (size_t)lstack_block * (sd.kd_depth + 1) * 12;
         if (lstack_block >= 64 && mask_words <= 1 && lds_stack <= 160 * 1024) {
             const int res = resident_blocks(k_trace<1, true, true>, lstack_block, lds_stack);
