@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--gather", default="rgba8", choices=["f64", "rgba8"],
                     help="what the image gather moves: rgba8 = the final 8-bit image (pixel_d2c on the device, what the "
                          "reference writes to disk), f64 = the double framebuffer (8x the bytes over xGMI)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the run, rank 0 renders the whole frame alone and compares it with the last gathered one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 code path on a "
                          "one-GPU box (all ranks share device 0, shards staged through host memory)")
@@ -171,32 +173,49 @@ def main():
 
     from ndt_amd.multi import RowGather
     gdev = "cpu" if rehearsal else "cuda"
-    rg64 = RowGather(height, width, 4, torch.float64, gdev, rank, world, dist)
-    rg8 = RowGather(height, width, 4, torch.uint8, gdev, rank, world, dist) if args.gather == "rgba8" else None
-    local = rg64.local if not rehearsal else torch.zeros_like(rg64.local, device="cuda")
-    local8 = None
-    if rg8 is not None:
-        local8 = rg8.local if not rehearsal else torch.zeros_like(rg8.local, device="cuda")
+    # Two gather buffers: the gather of frame k runs (RCCL's own stream) while frame k+1 is rendered, as an
+    # animation would be produced; every frame's gather is complete before the timed region ends (fence()).
+    n_buf = 2 if world > 1 else 1
+    gdtype = torch.uint8 if args.gather == "rgba8" else torch.float64
+    gath = [RowGather(height, width, 4, gdtype, gdev, rank, world, dist) for _ in range(n_buf)]
+    rows_max = gath[0].rows_max
+    direct = args.gather == "f64" and not rehearsal          # render straight into the gather buffer
+    frames64 = [g.local for g in gath] if direct else [torch.zeros((rows_max, width, 4), dtype=torch.float64, device="cuda")]
+    stage8 = torch.zeros((rows_max, width, 4), dtype=torch.uint8, device="cuda") if (rehearsal and args.gather == "rgba8") else None
+    state = {"k": 0, "pending": None}
+    torch.cuda.synchronize()                # the buffers above are filled on torch's stream, the renderer has its own
+
+    def drain():
+        g = state["pending"]
+        if g is not None:
+            g.finish()
+            if not rehearsal:
+                # finish() only orders torch's stream behind the gather; the renderer writes on its own stream
+                torch.cuda.current_stream().synchronize()
+            state["pending"] = None
 
     def step(profile):
-        st = gpu.render_device(local.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
+        k = state["k"]
+        state["k"] = k + 1
+        g = gath[k % n_buf]
+        f64 = frames64[k % len(frames64)]
+        st = gpu.render_device(f64.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
         if world > 1:
-            if rg8 is not None:
-                gpu.quantize_device(local.data_ptr(), local8.data_ptr(), rg64.rows_max * width)
+            drain()                         # frame k-1: gathered while frame k was rendered
+            if args.gather == "rgba8":
+                dst8 = stage8 if rehearsal else g.local
+                gpu.quantize_device(f64.data_ptr(), dst8.data_ptr(), rows_max * width)
                 gpu.synchronize()
                 if rehearsal:
-                    rg8.local.copy_(local8)
-                rg8.assemble()
-            else:
-                if rehearsal:
-                    rg64.local.copy_(local)
-                rg64.assemble()
-            # the gather runs on torch's collective stream, the next frame on the context's own stream:
-            # the shard buffers must not be rewritten before the gather has read them
-            torch.cuda.synchronize()
+                    g.local.copy_(stage8)
+            elif rehearsal:
+                g.local.copy_(f64)
+            g.start()
+            state["pending"] = g
         return st
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -283,6 +302,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth, args.cpu_threads)
         print(json.dumps(line), flush=True)
+    if args.verify and world > 1 and rank == 0:
+        whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")
+        want = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()            # torch fills on its stream, the renderer writes on its own
+        gpu.render_device(whole.data_ptr(), width, height, depth)
+        last = gath[(state["k"] - 1) % n_buf].image
+        if args.gather == "rgba8":
+            gpu.quantize_device(whole.data_ptr(), want.data_ptr(), height * width)
+            gpu.synchronize()
+        else:
+            want = whole
+        same = bool(torch.equal(last.cpu(), want.cpu()))
+        if not same:
+            bad = (last.cpu() != want.cpu()).any(dim=2)
+            rows = bad.any(dim=1).nonzero().flatten()
+            print("verify: %d pixels differ, rows %s ..." % (int(bad.sum()), rows[:8].tolist()), file=sys.stderr)
+        print("verify: gathered frame %s the single-GPU render" % ("==" if same else "!="), file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit("bench.py --verify: the gathered frame differs")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

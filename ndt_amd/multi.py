@@ -24,21 +24,38 @@ class RowGather:
         self.rows_max = padded_rows(height, world)
         self.local = torch.zeros((self.rows_max, width, channels), dtype=dtype, device=device)
         self.parts = None
+        self.work = None
         self.image = None
         if world > 1 and rank == dst:
             self.parts = [torch.empty_like(self.local) for _ in range(world)]
         if rank == dst:
             self.image = torch.empty((height, width, channels), dtype=dtype, device=device)
 
-    def assemble(self):
-        """Gather every rank's `local` rows to `dst` and de-interleave; returns the frame on dst."""
+    def start(self):
+        """Begin gathering this buffer's `local` rows to `dst` (asynchronous for world > 1).
+
+        The collective runs on the backend's own stream, so the caller may render the NEXT frame into
+        ANOTHER RowGather's `local` meanwhile; this one's `local` and `parts` must stay untouched until
+        `finish()` has returned and the current torch stream has been synchronised."""
+        if self.world > 1:
+            self.work = self.dist.gather(self.local, self.parts, dst=self.dst, async_op=True)
+
+    def finish(self):
+        """Wait for `start()`'s gather and de-interleave on dst; returns the frame on dst, None elsewhere."""
         if self.world == 1:
             self.image.copy_(self.local[:self.height])
             return self.image
-        self.dist.gather(self.local, self.parts, dst=self.dst)
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
         if self.rank != self.dst:
             return None
         for r in range(self.world):
             n = shard_rows(self.height, r, self.world)
             self.image[r::self.world] = self.parts[r][:n]
         return self.image
+
+    def assemble(self):
+        """Gather every rank's `local` rows to `dst` and de-interleave; returns the frame on dst."""
+        self.start()
+        return self.finish()
