@@ -256,6 +256,13 @@ int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step);
  * box, 0 when it has none (its faces are always scanned), <0 on NDT_E_*. */
 int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *rows);
 
+/* Diagnostic, host only: the boxes of the single faces of hcube `object` in the frame of its hull box
+ * (same derivation, one face at a time): the nested trace() visits only the faces whose box the ray
+ * meets.  face_rows receives n_faces x dims x { centre coordinate, half extent } (room for 63 faces);
+ * bit f of *possible is clear when face f can never be hit.  Returns the number of faces, 0 when the
+ * hcube has no face boxes (no hull box, or more than 63 faces), <0 on NDT_E_*. */
+int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double *face_rows, uint64_t *possible);
+
 /* The stream the context launches on (a hipStream_t), for callers that time with their own
  * events or order other work against it. */
 void *ndt_hip_stream(ndt_hip_ctx *ctx);

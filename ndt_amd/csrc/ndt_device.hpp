@@ -27,6 +27,7 @@
 #define NDT_F_USE_NORMALS 0x400     /* hfacet.c:283 */
 #define NDT_F_TRANSPARENT 0x800
 #define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_host.hip:hcube_hull_box) */
+#define NDT_F_FACEBOX     0x2000    /* ... followed by the mask of possible faces and every face's own box in that frame */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
 // light_type numbering of the reference, scene.h:23-31
@@ -668,6 +669,63 @@ template <int N> NDT_DEV bool hull_box_pass(const double *blob, int p, const dou
     return ok && t0 <= t1;
 }
 
+// The hull box test plus, for hcubes that carry them (NDT_F_FACEBOX), the same test against every face's own
+// box: returns 0 when the ray misses the hull box or every face box (skip the hcube), -1 when all faces are to be
+// scanned (no face boxes), otherwise the mask of the faces whose box the ray meets (bit f = nested primitive f,
+// at most 63 of them).  The projections u_k.o and 1/(u_k.v) of the hull test are shared by all the faces, so a
+// face costs N slab updates -- against ~20 orthotope intersections per hcube visit on the benchmark scene, of which
+// almost all missed.
+template <int N>
+NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N])
+{
+    double po[N], inv[N];       // u_k.o and 1/(u_k.v); 0 marks a ray parallel to slab k
+    double t0 = 0.0, t1 = NDT_DBL_MAX;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double u[N];
+        blob_vec<N>(blob, p + k * (N + 2), u);
+        po[k] = v_dot<N>(u, o);
+        const double a = po[k] - blob[p + k * (N + 2) + N];
+        const double d = v_dot<N>(u, v);
+        const double h = blob[p + k * (N + 2) + N + 1];
+        if (fabs(d) < 1e-200) {
+            inv[k] = 0.0;
+            if (fabs(a) > h) ok = false;        // parallel to the slab and outside it
+        } else {
+            inv[k] = 1.0 / d;
+            const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+            const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            if (lo > t0) t0 = lo;
+            if (hi < t1) t1 = hi;
+        }
+    }
+    if (!(ok && t0 <= t1)) return 0;
+    if (!face_boxes) return -1;
+    const int fr = p + N * (N + 2);
+    unsigned long long live = 0ull;
+    for (int f = 0; f < nf; ++f) {
+        const int q = fr + 1 + f * 2 * N;
+        double f0 = 0.0, f1 = NDT_DBL_MAX;
+        bool fok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double a = po[k] - blob[q + 2 * k];
+            const double h = blob[q + 2 * k + 1];
+            if (inv[k] == 0.0) {
+                if (fabs(a) > h) fok = false;
+            } else {
+                const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                if (lo > f0) f0 = lo;
+                if (hi < f1) f1 = hi;
+            }
+        }
+        if (fok && f0 <= f1) live |= 1ull << f;
+    }
+    return (long long)(live & (unsigned long long)__double_as_longlong(blob[fr]));
+}
+
 // ------------------------------------------------------------------ trace / kd-tree
 
 // Per-ray visit mask (the reference callocs obj_num bytes per ray, kd-tree.c:600).
@@ -747,6 +805,26 @@ template <int MW> struct VisitMask {
 #define NDT_COUNT(slot) (cnt[slot] += 1)
 /* wave-level occupancy of a loop body: iterations and active lanes (same value in every active lane) */
 #define NDT_OCC(slot) do { occ[2 * (slot)] += 1; occ[2 * (slot) + 1] += __popcll(__ballot(1)); } while (0)
+#elif defined(NDT_TAIL_PROBE)
+// diagnostic build only: iterations of the three loops and wall-clock time (100 MHz) per phase, per batch
+// (the per-phase clock reads and iteration counters only with NDT_TAIL_PROBE=2: they cost registers and stalls that
+// double the time of the batches they measure -- the launch / last-batch times of the plain probe are the data)
+#if NDT_TAIL_PROBE > 1
+#define NDT_STAMP(slot)                                                   \
+    do {                                                                  \
+        const unsigned long long now_ = wall_clock64();                   \
+        probe_t[slot] += now_ - probe_last;                               \
+        probe_last = now_;                                                \
+    } while (0)
+#else
+#define NDT_STAMP(slot) do { (void)probe_last; } while (0)
+#endif
+#define NDT_COUNT(slot) do { } while (0)
+#if NDT_TAIL_PROBE > 1
+#define NDT_OCC(slot) (probe_it[slot] += 1)
+#else
+#define NDT_OCC(slot) do { (void)probe_it; } while (0)
+#endif
 #else
 #define NDT_STAMP(slot) do { } while (0)
 #define NDT_COUNT(slot) do { } while (0)
@@ -767,11 +845,15 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
                       , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
+#elif defined(NDT_TAIL_PROBE)
+                      , unsigned int (&probe_it)[3], unsigned long long (&probe_t)[8]
 #endif
                       , KdStackLds ls = KdStackLds{})
 {
 #ifdef NDT_PHASE_TIMING
     unsigned long long ph_last = __builtin_readcyclecounter();
+#elif defined(NDT_TAIL_PROBE)
+    unsigned long long probe_last = NDT_TAIL_PROBE > 1 ? wall_clock64() : 0ull;
 #endif
     double v_inv[N];
 #pragma unroll
@@ -811,6 +893,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     // nested (hcube) list
     bool in_sub = false;
     int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
+    long long sub_live = -1;                // faces still to scan, bit 0 = the one at sub_i (all ones: every face)
     double sub_min = -1;
 
     if (sd.n_inf > 0) {
@@ -985,8 +1068,19 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 } else {
                     int id, flags;
                     blob_ref(blob, in_sub ? sd.off_child + sub_i : sec + pos, id, flags);
-                    sub_i += in_sub ? 1 : 0;
-                    pos += in_sub ? 0 : 1;
+                    if (in_sub) {
+                        // on to the next face whose box the ray meets (arithmetic shifts: all ones stays all ones)
+                        const long long rest = sub_live >> 1;
+                        if (rest == 0) {
+                            sub_i = sub_end;
+                        } else {
+                            const int skip = __ffsll(rest) - 1;
+                            sub_i += 1 + skip;
+                            sub_live = rest >> skip;
+                        }
+                    } else {
+                        pos += 1;
+                    }
                     bool fresh = true;
                     if (!in_sub && !list_is_inf) fresh = !mask.test_and_set(id);    // object.c:707-713
                     if (fresh) {
@@ -996,12 +1090,19 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, id, o, v, gate_min)) {
                             if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
                               // composites only occur in outer lists (validated at upload)
-                              if (!(flags & NDT_F_BOX) ||
-                                  hull_box_pass<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1), o, v)) {
+                              const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
+                              const int nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+                              long long live = -1;
+                              if (flags & NDT_F_BOX)
+                                  live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1),
+                                                       (flags & NDT_F_FACEBOX) != 0, nf, o, v);
+                              if (live != 0) {
+                                const int skip = __ffsll(live) - 1;
                                 in_sub = true;
                                 sub_owner = id;
-                                sub_i = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
-                                sub_end = sub_i + blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+                                sub_i = first + skip;
+                                sub_end = first + nf;
+                                sub_live = live >> skip;
                                 sub_min = -1;
                                 sub_prim = -1;
                               }

@@ -39,7 +39,14 @@ static int fail(int code, const char *fmt, ...)
 
 extern "C" const char *ndt_hip_last_error(void) { return g_err; }
 extern "C" int ndt_hip_abi_version(void) { return NDT_HIP_ABI_VERSION; }
-static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows);
+struct HullFaces {
+    // per face of the hcube, in the hull box's frame: N x { centre coordinate, half extent } -- the face's own
+    // box, same derivation and margin as the hull box; possible bit f clear = face f can never be hit
+    std::vector<double> rows;
+    unsigned long long possible = 0;
+    int n_faces = 0;
+};
+static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);
 
 extern "C" int ndt_hip_hcube_hull_box(const ndt_flat_scene *fs, int32_t object, double *rows_out)
 {
@@ -58,6 +65,20 @@ extern "C" int ndt_hip_hcube_hull_box(const ndt_flat_scene *fs, int32_t object, 
     if (!hcube_hull_box(fs, o, fs->dims, rows)) return 0;
     memcpy(rows_out, rows.data(), rows.size() * sizeof(double));
     return 1;
+}
+
+extern "C" int ndt_hip_hcube_face_boxes(const ndt_flat_scene *fs, int32_t object, double *face_rows, uint64_t *possible)
+{
+    if (!face_rows || !possible) return fail(NDT_E_INVALID, "null argument");
+    std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
+    const int rc = ndt_hip_hcube_hull_box(fs, object, hull.data());      // validates the arguments
+    if (rc <= 0) return rc;
+    std::vector<double> rows;
+    HullFaces hf;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    memcpy(face_rows, hf.rows.data(), hf.rows.size() * sizeof(double));
+    *possible = hf.possible;
+    return hf.n_faces;
 }
 
 extern "C" int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step)
@@ -335,6 +356,7 @@ static int kd_preorder(const ndt_flat_scene *fs, int node, int depth, std::vecto
 #define NDT_HULL_MARGIN 0.02
 #define NDT_HULL_DELTA 0.01485      /* sqrt(2e-4) * 1.05 */
 #define NDT_HULL_EPS 1.1e-4
+#define NDT_HULL_MAX_FACES 63       /* face boxes: one bit per face in a 64-bit word whose top bit stays clear (trace_kd) */
 
 // cyclic Jacobi: a (m x m, symmetric, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of w
 static void jacobi_eig(std::vector<double> &a, std::vector<double> &w, int m)
@@ -436,11 +458,13 @@ static bool face_region_corners(const double *pos, const double *dir, int m, int
     return true;
 }
 
-static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows)
+static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces)
 {
     std::vector<double> pts;
+    std::vector<size_t> face_begin;             // first corner point of every face (its region's corners are consecutive)
     std::vector<std::vector<double>> axes;      // unit face axes, for the aligned candidate frame
     for (int k = 0; k < o.n_obj; ++k) {
+        face_begin.push_back(pts.size() / n);
         const ndt_flat_object &f = fs->objects[fs->obj_refs[o.obj_off + k]];
         if (f.type != NDT_OBJ_ORTHOTOPE || f.n_flag < 1 || f.n_pos < 1) return false;
         if (f.flag_off < 0 || (int64_t)f.flag_off + f.n_flag > fs->n_flags) return false;
@@ -537,6 +561,34 @@ static bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, i
     }
     if (best < 0) return false;
     rows = best_rows;
+    if (faces) {
+        // Every face's own box in the chosen frame.  The hull box is the union of these: a ray that misses box f
+        // cannot produce a point face f's intersect() accepts (same argument, one face at a time), so the device
+        // scans only the faces whose box the ray meets -- of the 2-D faces of a 4-D hcube, usually none or two.
+        faces->rows.clear();
+        faces->possible = 0;
+        faces->n_faces = 0;
+        if (o.n_obj <= NDT_HULL_MAX_FACES) {
+            faces->n_faces = o.n_obj;
+            face_begin.push_back(n_pts);
+            for (int k = 0; k < o.n_obj; ++k) {
+                const size_t p0 = face_begin[k], p1 = face_begin[k + 1];
+                if (p1 > p0) faces->possible |= 1ull << k;
+                for (int a = 0; a < n; ++a) {
+                    double lo = 1e300, hi = -1e300;
+                    for (size_t i = p0; i < p1; ++i) {
+                        double d = 0;
+                        for (int c = 0; c < n; ++c) d += pts[i * n + c] * rows[(size_t)a * (n + 2) + c];
+                        if (d < lo) lo = d;
+                        if (d > hi) hi = d;
+                    }
+                    if (p1 == p0) lo = hi = 0;
+                    faces->rows.push_back(0.5 * (lo + hi));
+                    faces->rows.push_back(0.5 * (hi - lo) + NDT_HULL_MARGIN);
+                }
+            }
+        }
+    }
     return true;
 }
 
@@ -714,9 +766,16 @@ static int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             aux0 = child_first[i];
             aux1 = o.n_obj;
             std::vector<double> rows;
-            if (!getenv("NDT_HIP_NO_HULL_BOX") && hcube_hull_box(fs, o, n, rows)) {
+            HullFaces hf;
+            if (!getenv("NDT_HIP_NO_HULL_BOX") && hcube_hull_box(fs, o, n, rows, &hf)) {
                 flags |= NDT_F_BOX;
                 for (double x : rows) b.push(x);
+                if (hf.n_faces > 0 && !getenv("NDT_HIP_NO_FACE_BOX")) {
+                    // { possible-faces mask } + per face N x { centre, half extent }
+                    flags |= NDT_F_FACEBOX;
+                    b.push_ints((int)(hf.possible & 0xffffffffull), (int)(hf.possible >> 32));
+                    for (double x : hf.rows) b.push(x);
+                }
             } else {
                 b.push(0.0);
             }
@@ -955,7 +1014,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
     if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.dbg, 64))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
     if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -1186,7 +1245,7 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 64 * 8 * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemsetAsync(ws.dbg, 0, 64 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(ws.dbg, 0, 160 * sizeof(unsigned long long), s));
         // work-queue heads of every launch of the frame + both parities of the shadow-segment counters
         HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)(NDT_CNT_TOTAL - NDT_CNT_QUEUE) * sizeof(int), s));
         // The stream is never synchronised inside a frame: the range of every bounce is published
@@ -1346,8 +1405,20 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             if (getenv("NDT_HIP_DEBUG_LEVELS")) {
                 for (int b = 0; b < levels_used; ++b)
                     fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
-                unsigned long long d[64];
-                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[4]) {
+                unsigned long long d[160];
+                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) d[4] = 0;
+                for (int l = 0; l < 6 && d[4] == 0; ++l) {
+                    // NDT_TAIL_PROBE builds only (make -C ndt_amd/csrc tailprobe); times in us from the first wavefront's start
+                    const unsigned long long *q = d + 64 + 16 * l;
+                    if (!q[10]) continue;
+                    const unsigned long long t0 = ~q[0], dry = ~q[1], end = q[2] >> 20;
+                    auto low = [&](int i) { return (double)(q[i] & 0xfffffull); };
+                    fprintf(stderr, "ndt_hip: trace launch %d: first wavefront out of work at %.1f us, last one done at %.1f us; its last batch: %.1f us, "
+                            "%.0f T / %.0f G / %.0f I iterations, %.1f us in T, %.1f in G, %.1f in I, %.1f at list ends\n",
+                            l, (dry - t0) / 100.0, (end - t0) / 100.0, low(2) / 100.0, low(3), low(4), low(5),
+                            low(6) / 100.0, low(7) / 100.0, low(8) / 100.0, low(9) / 100.0);
+                }
+                if (d[4]) {
                     // NDT_PHASE_TIMING builds only (make -C ndt_amd/csrc timing)
                     fprintf(stderr, "ndt_hip: wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
                     fprintf(stderr, "ndt_hip: per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",

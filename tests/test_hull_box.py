@@ -4,8 +4,9 @@ trace() over the hcube's faces (hcube.c:241).  That is only legitimate if no poi
 reference can return for a face lies outside the box.  Checked here
   * on the CPU: every hit the oracle reports on an hcube, for rays aimed at its faces, lies
     inside the box with the slack the derivation promises (margin 0.02 vs reach 0.01485);
-  * on the GPU: the same rays give bit-identical answers with the oracle, and with the box
-    switched off (NDT_HIP_NO_HULL_BOX=1 at upload).
+  * on the GPU: the same rays give bit-identical answers with the oracle, with the boxes
+    switched off (NDT_HIP_NO_HULL_BOX=1 at upload) and with the hull box alone (NDT_HIP_NO_FACE_BOX=1).
+The same holds one face at a time for the per-face boxes: only the faces whose box a ray meets are scanned.
 """
 import os
 
@@ -88,6 +89,41 @@ def test_every_oracle_hit_on_an_hcube_lies_inside_its_hull_box(oracle, name):
     assert n_hits > 15          # the aimed rays do reach the faces (skewed ones of random.c included)
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_every_oracle_hit_on_an_hcube_lies_inside_a_face_box(oracle, name):
+    """The per-face boxes (ndt_hip_hcube_face_boxes): the device scans only the faces whose box the ray
+    meets, so every hit the reference reports must lie inside the box of a face that can be hit."""
+    from ndt_amd.hip import hcube_hull_box, hcube_face_boxes
+    fs = golden(name).scene
+    hs = hcubes(fs)
+    if not hs:
+        pytest.skip("no hcube in this scene")
+    boxes = {h: hcube_hull_box(fs, h) for h in hs}
+    faces = {h: hcube_face_boxes(fs, h) for h in hs}
+    if all(f is None for f in faces.values()):
+        # more than 63 faces (a 5-D hcube of 2-faces has 80): hull box only
+        assert all(fs.objects[h]["n_obj"] > 63 or boxes[h] is None for h in hs)
+        pytest.skip("no hcube of this scene has face boxes")
+    rays = aimed_rays(fs, boxes.get, seed=17)
+    obj, hit, _ = oracle.trace(fs, rays)
+    checked = 0
+    for h in hs:
+        sel = obj == h
+        if faces[h] is None or not sel.any():
+            continue
+        ax = boxes[h][0]
+        centre, half, live = faces[h]
+        assert len(centre) == fs.objects[h]["n_obj"]
+        # the hull box is the union of the face boxes
+        lo, hi = (centre - half)[live].min(axis=0), (centre + half)[live].max(axis=0)
+        assert np.allclose(0.5 * (lo + hi), boxes[h][1], atol=1e-12) and np.allclose(0.5 * (hi - lo), boxes[h][2], atol=1e-12)
+        coord = hit[sel] @ ax.T                                         # [hits, N] in the frame
+        inside = (np.abs(coord[:, None, :] - centre[None]) <= (half - SLACK)[None]).all(axis=2) & live[None]
+        assert inside.any(axis=1).all(), "hcube %d: a reference hit lies in no face box" % h
+        checked += int(sel.sum())
+    assert checked > 15
+
+
 def test_hull_box_of_a_non_hcube_is_an_error():
     from ndt_amd.hip import hcube_hull_box, NdtHipError
     fs = golden("c3_random4d").scene
@@ -115,8 +151,15 @@ def test_cull_changes_nothing_on_the_device(oracle, name):
             plain = gpu.trace_rays(rays)
         finally:
             del os.environ["NDT_HIP_NO_HULL_BOX"]
+        os.environ["NDT_HIP_NO_FACE_BOX"] = "1"          # hull box only, every face scanned
+        try:
+            gpu.upload_scene(fs)
+            hull_only = gpu.trace_rays(rays)
+        finally:
+            del os.environ["NDT_HIP_NO_FACE_BOX"]
     finally:
         gpu.close()
-    for a, b, c in zip(got, plain, want):
+    for a, b, c, d in zip(got, plain, want, hull_only):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)
+        assert np.array_equal(a, d)
