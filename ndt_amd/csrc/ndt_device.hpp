@@ -805,26 +805,6 @@ template <int MW> struct VisitMask {
 #define NDT_COUNT(slot) (cnt[slot] += 1)
 /* wave-level occupancy of a loop body: iterations and active lanes (same value in every active lane) */
 #define NDT_OCC(slot) do { occ[2 * (slot)] += 1; occ[2 * (slot) + 1] += __popcll(__ballot(1)); } while (0)
-#elif defined(NDT_TAIL_PROBE)
-// diagnostic build only: iterations of the three loops and wall-clock time (100 MHz) per phase, per batch
-// (the per-phase clock reads and iteration counters only with NDT_TAIL_PROBE=2: they cost registers and stalls that
-// double the time of the batches they measure -- the launch / last-batch times of the plain probe are the data)
-#if NDT_TAIL_PROBE > 1
-#define NDT_STAMP(slot)                                                   \
-    do {                                                                  \
-        const unsigned long long now_ = wall_clock64();                   \
-        probe_t[slot] += now_ - probe_last;                               \
-        probe_last = now_;                                                \
-    } while (0)
-#else
-#define NDT_STAMP(slot) do { (void)probe_last; } while (0)
-#endif
-#define NDT_COUNT(slot) do { } while (0)
-#if NDT_TAIL_PROBE > 1
-#define NDT_OCC(slot) (probe_it[slot] += 1)
-#else
-#define NDT_OCC(slot) do { (void)probe_it; } while (0)
-#endif
 #else
 #define NDT_STAMP(slot) do { } while (0)
 #define NDT_COUNT(slot) do { } while (0)
@@ -845,15 +825,11 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
                       , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
-#elif defined(NDT_TAIL_PROBE)
-                      , unsigned int (&probe_it)[3], unsigned long long (&probe_t)[8]
 #endif
                       , KdStackLds ls = KdStackLds{})
 {
 #ifdef NDT_PHASE_TIMING
     unsigned long long ph_last = __builtin_readcyclecounter();
-#elif defined(NDT_TAIL_PROBE)
-    unsigned long long probe_last = NDT_TAIL_PROBE > 1 ? wall_clock64() : 0ull;
 #endif
     double v_inv[N];
 #pragma unroll

@@ -1015,6 +1015,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
     if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return rc;
     if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -1246,6 +1247,8 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 64 * 8 * sizeof(unsigned long long), s));
         HIP_TRY(hipMemsetAsync(ws.dbg, 0, 160 * sizeof(unsigned long long), s));
+        if (prof && getenv("NDT_HIP_EXIT_PROBE"))
+            HIP_TRY(hipMemsetAsync(ws.exit_log, 0, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS * sizeof(unsigned int), s));
         // work-queue heads of every launch of the frame + both parities of the shadow-segment counters
         HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)(NDT_CNT_TOTAL - NDT_CNT_QUEUE) * sizeof(int), s));
         // The stream is never synchronised inside a frame: the range of every bounce is published
@@ -1272,6 +1275,8 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
+            static const bool exit_probe = getenv("NDT_HIP_EXIT_PROBE") != nullptr;
+            tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                 HIP_TRY(hipEventRecord(a, s));
@@ -1407,16 +1412,44 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                     fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
                 unsigned long long d[160];
                 if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) d[4] = 0;
-                for (int l = 0; l < 6 && d[4] == 0; ++l) {
-                    // NDT_TAIL_PROBE builds only (make -C ndt_amd/csrc tailprobe); times in us from the first wavefront's start
-                    const unsigned long long *q = d + 64 + 16 * l;
-                    if (!q[10]) continue;
-                    const unsigned long long t0 = ~q[0], dry = ~q[1], end = q[2] >> 20;
-                    auto low = [&](int i) { return (double)(q[i] & 0xfffffull); };
-                    fprintf(stderr, "ndt_hip: trace launch %d: first wavefront out of work at %.1f us, last one done at %.1f us; its last batch: %.1f us, "
-                            "%.0f T / %.0f G / %.0f I iterations, %.1f us in T, %.1f in G, %.1f in I, %.1f at list ends\n",
-                            l, (dry - t0) / 100.0, (end - t0) / 100.0, low(2) / 100.0, low(3), low(4), low(5),
-                            low(6) / 100.0, low(7) / 100.0, low(8) / 100.0, low(9) / 100.0);
+                if (getenv("NDT_HIP_EXIT_PROBE")) {
+                    // the life of every wavefront of every trace launch: when the queue runs dry (first exit), how long the
+                    // rest keeps going, and how much of that is the last wavefront's last batch
+                    std::vector<unsigned int> log((size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS);
+                    if (hipMemcpy(log.data(), ws.exit_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess)
+                        for (int l = 0; l < NDT_EXIT_LOG_LAUNCHES && l < launches; ++l) {
+                            const unsigned int *q = log.data() + (size_t)l * NDT_EXIT_LOG_WORDS;
+                            unsigned int t0 = 0;
+                            int n_w = 0;
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 3; ++w)
+                                if (q[3 * w + 2]) {
+                                    if (!n_w || (int)(q[3 * w] - t0) < 0) t0 = q[3 * w];
+                                    ++n_w;
+                                }
+                            int hist[64] = { 0 };
+                            double first = 1e30, last = 0, last_batch = 0, start_spread = 0;
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 3; ++w)
+                                if (q[3 * w + 2]) {
+                                    const double st_us = (q[3 * w] - t0) / 100.0, ex_us = (q[3 * w + 2] - t0) / 100.0;
+                                    if (st_us > start_spread) start_spread = st_us;
+                                    if (ex_us < first) first = ex_us;
+                                    if (ex_us > last) {
+                                        last = ex_us;
+                                        last_batch = (q[3 * w + 2] - q[3 * w + 1]) / 100.0;
+                                    }
+                                    const int bin = (int)(ex_us / 16.0);
+                                    ++hist[bin > 63 ? 63 : bin];
+                                }
+                            std::string line;
+                            for (int bin = 0; bin < 64; ++bin)
+                                if (hist[bin]) {
+                                    char buf[48];
+                                    snprintf(buf, sizeof buf, " %d-%d:%d", bin * 16, bin * 16 + 16, hist[bin]);
+                                    line += buf;
+                                }
+                            fprintf(stderr, "ndt_hip: trace launch %d: %d wavefronts start within %.1f us; first out of work at %.1f us, last at %.1f us (its last batch: %.1f us); exits per 16 us:%s\n",
+                                    l, n_w, start_spread, first, last, last_batch, line.c_str());
+                        }
                 }
                 if (d[4]) {
                     // NDT_PHASE_TIMING builds only (make -C ndt_amd/csrc timing)

@@ -268,14 +268,9 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         mask.ext_stride = (int)ws.mask_slab_lanes;
     }
     const int lane = __lane_id();
-#ifdef NDT_TAIL_PROBE
-    // diagnostic build (make -C ndt_amd/csrc tailprobe): when did the queue run dry, when did the last wavefront
-    // finish, and what did its last batch consist of
-    const unsigned long long probe_start = wall_clock64();
-    unsigned long long probe_batch = probe_start;
-    unsigned int probe_it[3] = { 0, 0, 0 };
-    unsigned long long probe_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
+    // NDT_HIP_EXIT_PROBE: when does every wavefront start, start its last batch, and run out of work
+    const unsigned int probe_start = job.exit_log ? (unsigned int)wall_clock64() : 0u;
+    unsigned int probe_batch = probe_start;
 #ifdef NDT_PHASE_TIMING
     // diagnostic build: everything is accumulated in registers and flushed once per wavefront at
     // the end of the kernel, so that the counters' atomics do not sit inside the phases they measure
@@ -344,11 +339,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             }
         }
         if (b < 0) break;
-#ifdef NDT_TAIL_PROBE
-        probe_batch = wall_clock64();
-        probe_it[0] = probe_it[1] = probe_it[2] = 0;
-        for (int i = 0; i < 8; ++i) probe_t[i] = 0;
-#endif
+        if (job.exit_log) probe_batch = (unsigned int)wall_clock64();
         long long g;
         const bool in_seg = b >= dense_batches;         // wave-uniform
         if (in_seg) {
@@ -429,11 +420,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             prim = -1;
         } else
 #endif
-#ifdef NDT_TAIL_PROBE
-        trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, probe_it, probe_t, kstack);
-#else
         trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
-#endif
 #endif
 #ifdef NDT_TRACE_SKIP_KNOB
         if (job.skip_trace == 2 && obj == -1) continue;
@@ -441,26 +428,15 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
         part.out_obj[g] = obj;
         part.out_prim[g] = prim;
     }
-#ifdef NDT_TAIL_PROBE
-    if (ws.dbg) {
-        // 100 MHz ticks.  [0] ~earliest start, [1] ~earliest "queue empty", [2..] latest end packed with that wavefront's
-        // last batch: its duration, its T / G / I iterations and the time in T / G / I / list ends (maxima over its lanes)
-        const unsigned long long now = wall_clock64();
-        unsigned long long *d = ws.dbg + 64 + 16 * (job.levels ? job.dense_level : 0);
-        unsigned long long v8[8] = { now - probe_batch, probe_it[0], probe_it[1], probe_it[2], probe_t[0], probe_t[1], probe_t[2], probe_t[3] };
-        for (int i = 1; i < 8; ++i)
-            for (int sft = 32; sft > 0; sft >>= 1) {
-                const unsigned long long o2 = __shfl_xor(v8[i], sft, 64);
-                v8[i] = o2 > v8[i] ? o2 : v8[i];
-            }
-        if (lane == 0) {
-            atomicMax(&d[0], ~probe_start);
-            atomicMax(&d[1], ~now);
-            for (int i = 0; i < 8; ++i) atomicMax(&d[2 + i], (now << 20) | (v8[i] > 0xfffffull ? 0xfffffull : v8[i]));
-            atomicAdd(&d[10], 1ull);
+    if (job.exit_log && lane == 0) {
+        // one private slot per wavefront: shared counters would serialise the very exits they measure
+        const unsigned int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+        if (3 * w + 2 < NDT_EXIT_LOG_WORDS) {
+            job.exit_log[3 * w] = probe_start;
+            job.exit_log[3 * w + 1] = probe_batch;
+            job.exit_log[3 * w + 2] = (unsigned int)wall_clock64() | 1u;
         }
     }
-#endif
 #ifdef NDT_PHASE_TIMING
     ph[6] += __builtin_readcyclecounter() - out_last;
     if (ws.dbg) {

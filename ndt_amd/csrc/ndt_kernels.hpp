@@ -46,6 +46,7 @@ struct Workspace {
     unsigned long long *mask_slab;  // visit masks for scenes too big for registers
     long long mask_slab_lanes;
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
+    unsigned int *exit_log;         // [NDT_EXIT_LOG_LAUNCHES][NDT_EXIT_LOG_WORDS], NDT_HIP_EXIT_PROBE
     LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
     // the same table in host-visible (mapped, coherent) memory + one tag per entry: k_level_step
     // posts bounce b+1 here, the host polls the tag instead of synchronising the stream
@@ -105,7 +106,10 @@ struct TraceJob {
     int *queue;                 // device-side work-queue heads for this launch (zeroed by the host)
     int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
     int skip_trace;             // diagnostic build only: pop, load and store but do not traverse
+    unsigned int *exit_log;     // NDT_HIP_EXIT_PROBE: {start, start of the last batch, exit} per wavefront (100 MHz clock, low words)
 };
+#define NDT_EXIT_LOG_WORDS 12288    /* per launch: 3 words x 4096 wavefronts */
+#define NDT_EXIT_LOG_LAUNCHES 6
 
 
 // One table per compiled dimension.
