@@ -1016,6 +1016,7 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
     if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
     if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return rc;
+    if (getenv("NDT_HIP_SHADE_PROBE") && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return rc;
     if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -1301,6 +1302,22 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         }
         long long upper = rg.n_primary;         // node count of the bounce
         std::vector<long long> level_nodes;
+        // NDT_HIP_SHADE_PROBE=<k>: the k-th shade launch of the frame logs the life of each of its wavefronts
+        static const int shade_probe = getenv("NDT_HIP_SHADE_PROBE") ? atoi(getenv("NDT_HIP_SHADE_PROBE")) : -1;
+        int shade_launch = 0;
+        long long shade_probe_finish_waves = 0;         // wavefronts of the lighting part of the probed launch
+        long long shade_probe_emit_waves = 0;           // ... and of the shading part behind it (pair launches)
+        auto shade_ws = [&](long long finish_nodes, long long emit_nodes_behind = 0) {
+            Workspace w = ws;
+            if (shade_launch++ != shade_probe || !prof) {
+                w.shade_log = nullptr;
+            } else {
+                shade_probe_finish_waves = (finish_nodes + 255) / 256 * 4;
+                shade_probe_emit_waves = (emit_nodes_behind + 255) / 256 * 4;
+                (void)hipMemsetAsync(w.shade_log, 0, (size_t)2 * NDT_SHADE_LOG_WAVES * sizeof(unsigned int), s);
+            }
+            return w;
+        };
         static const bool fuse_shade = !(getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR")));
         int pending_finish = -1;                // bounce whose lighting has not been launched yet
         long long pending_upper = 0;
@@ -1326,14 +1343,14 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             // hit points, shadow rays of this bounce, and the rays of the next bounce -- in the same launch as the
             // lighting of the previous bounce, which is waiting for the shadow answers the last trace launch produced
             if (pending_finish >= 0 && fuse_shade) {
-                kt->shade_pair(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper, upper);
+                kt->shade_pair(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper, upper), rg, pending_finish, pending_upper, upper);
                 pending_finish = -1;
             } else {
                 if (pending_finish >= 0) {
-                    kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper);
+                    kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
                     pending_finish = -1;
                 }
-                kt->shade_emit(s, ctx->d_blob, ctx->sd, ws, rg, b, upper);
+                kt->shade_emit(s, ctx->d_blob, ctx->sd, shade_ws(0), rg, b, upper);
             }
             hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
             long long next_upper = 2 * upper;           // each node spawns at most two
@@ -1356,7 +1373,7 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             pending_finish = b;
             pending_upper = upper;
         }
-        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, ws, rg, pending_finish, pending_upper);
+        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
             for (int b = n_run; b-- > 0;) {
@@ -1412,6 +1429,45 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                     fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
                 unsigned long long d[160];
                 if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) d[4] = 0;
+                if (shade_probe >= 0 && ws.shade_log) {
+                    std::vector<unsigned int> log((size_t)2 * NDT_SHADE_LOG_WAVES);
+                    if (hipMemcpy(log.data(), ws.shade_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+                        unsigned int t0 = 0;
+                        bool any = false;
+                        for (int w = 0; w < NDT_SHADE_LOG_WAVES; ++w)
+                            if (log[2 * w + 1] && (!any || (int)(log[2 * w] - t0) < 0)) {
+                                t0 = log[2 * w];
+                                any = true;
+                            }
+                        for (int part = 0; part < 2; ++part) {
+                            // part 0: lighting (shade_finish) wavefronts, part 1: shading (shade_emit) wavefronts
+                            int hist[48] = { 0 }, n_w = 0;
+                            double sum = 0, longest = 0, last_start = 0, last_end = 0;
+                            for (long long w = 0; w < NDT_SHADE_LOG_WAVES; ++w) {
+                                const bool lighting = w < shade_probe_finish_waves;
+                                if (!log[2 * w + 1] || lighting != (part == 0)) continue;
+                                const double st_us = (log[2 * w] - t0) / 100.0, dur = (log[2 * w + 1] - log[2 * w]) / 100.0;
+                                ++n_w;
+                                sum += dur;
+                                if (dur > longest) longest = dur;
+                                if (st_us > last_start) last_start = st_us;
+                                if (st_us + dur > last_end) last_end = st_us + dur;
+                                const int bin = (int)(dur / 4.0);
+                                ++hist[bin > 47 ? 47 : bin];
+                            }
+                            if (!n_w) continue;
+                            std::string line;
+                            for (int bin = 0; bin < 48; ++bin)
+                                if (hist[bin]) {
+                                    char buf[48];
+                                    snprintf(buf, sizeof buf, " %d-%d:%d", bin * 4, bin * 4 + 4, hist[bin]);
+                                    line += buf;
+                                }
+                            fprintf(stderr, "ndt_hip: shade launch %d, %s: %d wavefronts, mean life %.1f us, longest %.1f us, last start at %.1f us, last end at %.1f us; lives per 4 us:%s\n",
+                                    shade_probe, part == 0 ? "lighting" : "shading", n_w, sum / n_w, longest, last_start, last_end, line.c_str());
+                        }
+                    }
+                }
                 if (getenv("NDT_HIP_EXIT_PROBE")) {
                     // the life of every wavefront of every trace launch: when the queue runs dry (first exit), how long the
                     // rest keeps going, and how much of that is the last wavefront's last batch

@@ -649,6 +649,9 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             ws.count[g] = 1;
         }
     }
+    // a wavefront of background only (two thirds of the primaries' wavefronts on the benchmark frame) is done here:
+    // no light fires, nothing spawns, and every collective below would come out empty
+    if (__ballot(shaded) == 0ull) return;
     // One shadow ray per light that passes the same-side / cone tests.  The queue is segmented
     // by light: the rays a wavefront later traces then share their origin (the light) and aim
     // at neighbouring hit points, instead of interleaving five unrelated origins.  Within a
@@ -792,6 +795,19 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     NDT_SEC_END(52);
 }
 
+// NDT_HIP_SHADE_PROBE: life of every wavefront of one shade launch, in private slots
+#define NDT_SHADE_LOG_BEGIN() const unsigned int shade_t0 = ws.shade_log ? (unsigned int)wall_clock64() : 0u
+#define NDT_SHADE_LOG_END()                                                                   \
+    do {                                                                                      \
+        if (ws.shade_log && (threadIdx.x & 63) == 0) {                                        \
+            const unsigned int w_ = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;        \
+            if (w_ < NDT_SHADE_LOG_WAVES) {                                                   \
+                ws.shade_log[2 * w_] = shade_t0;                                              \
+                ws.shade_log[2 * w_ + 1] = (unsigned int)wall_clock64() | 1u;                 \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+
 // The bounce's range comes from the device-side table; the grid is sized for the host's upper
 // bound, workgroups past the end leave at once.  (A grid-stride loop here cost 50 VGPRs and
 // half the occupancy.)
@@ -799,7 +815,11 @@ __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDes
 {
     const LevelRange lr = ws.levels[level];
     const long long base = (long long)blockIdx.x * blockDim.x;
-    if (base < lr.count) shade_emit_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+    if (base < lr.count) {
+        NDT_SHADE_LOG_BEGIN();
+        shade_emit_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+        NDT_SHADE_LOG_END();
+    }
 }
 
 // ------------------------------------------------------------------ shading, second half
@@ -901,21 +921,35 @@ __global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, Sce
 {
     const LevelRange lr = ws.levels[level];
     const long long base = (long long)blockIdx.x * blockDim.x;
-    if (base < lr.count) shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+    if (base < lr.count) {
+        NDT_SHADE_LOG_BEGIN();
+        shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+        NDT_SHADE_LOG_END();
+    }
 }
 
-// lighting of bounce `level` in the first n_finish workgroups, shading of bounce level+1 in the rest
+// lighting of bounce `level` in the first n_finish workgroups, shading of bounce level+1 in the rest.  (The other way
+// round -- the long-lived shading wavefronts first -- was measured: they then all contend for the segment counters at
+// once and live 22-32 us instead of 16-19, and the launch takes 20-30 % longer.)
 __global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
                                                        unsigned n_finish)
 {
     if (blockIdx.x < n_finish) {
         const LevelRange lr = ws.levels[level];
         const long long base = (long long)blockIdx.x * blockDim.x;
-        if (base < lr.count) shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+        if (base < lr.count) {
+            NDT_SHADE_LOG_BEGIN();
+            shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+            NDT_SHADE_LOG_END();
+        }
     } else {
         const LevelRange lr = ws.levels[level + 1];
         const long long base = (long long)(blockIdx.x - n_finish) * blockDim.x;
-        if (base < lr.count) shade_emit_node(blob, sd, ws, rg, lr, level + 1, base + threadIdx.x);
+        if (base < lr.count) {
+            NDT_SHADE_LOG_BEGIN();
+            shade_emit_node(blob, sd, ws, rg, lr, level + 1, base + threadIdx.x);
+            NDT_SHADE_LOG_END();
+        }
     }
 }
 

@@ -47,6 +47,7 @@ struct Workspace {
     long long mask_slab_lanes;
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
     unsigned int *exit_log;         // [NDT_EXIT_LOG_LAUNCHES][NDT_EXIT_LOG_WORDS], NDT_HIP_EXIT_PROBE
+    unsigned int *shade_log;        // NDT_HIP_SHADE_PROBE: {start, end} per wavefront of ONE shade launch (set for that launch only)
     LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
     // the same table in host-visible (mapped, coherent) memory + one tag per entry: k_level_step
     // posts bounce b+1 here, the host polls the tag instead of synchronising the stream
@@ -110,6 +111,7 @@ struct TraceJob {
 };
 #define NDT_EXIT_LOG_WORDS 12288    /* per launch: 3 words x 4096 wavefronts */
 #define NDT_EXIT_LOG_LAUNCHES 6
+#define NDT_SHADE_LOG_WAVES 131072  /* wavefronts the shade probe has slots for */
 
 
 // One table per compiled dimension.
