@@ -121,7 +121,8 @@ struct ndt_hip_ctx {
     LevelRange *d_mail = nullptr;   // the device's view of the two
     unsigned long long *d_mail_tag = nullptr;
     unsigned long long frame_tag = 0;
-    unsigned long long *h_ref = nullptr;   // pinned, 64 x 8
+    unsigned long long *h_done = nullptr;   // mapped + coherent: the frame's closing record (k_frame_done), [7] = its tag
+    unsigned long long *d_done = nullptr;
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -167,14 +168,10 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail_tag, ctx->h_mail_tag, 0);
     if (e == hipSuccess) memset(ctx->h_mail_tag, 0, (NDT_MAX_LEVELS + 2) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_done, 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_done, ctx->h_done, 0);
+    if (e == hipSuccess) memset(ctx->h_done, 0, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) {
-        (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return fail(NDT_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
-    }
-    e = hipHostMalloc((void **)&ctx->h_ref, 64 * 8 * sizeof(unsigned long long), hipHostMallocDefault);
-    if (e != hipSuccess) {
-        (void)hipHostFree(ctx->h_counters);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(NDT_E_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
@@ -207,7 +204,7 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     if (ctx->h_levels) (void)hipHostFree(ctx->h_levels);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     if (ctx->h_mail_tag) (void)hipHostFree(ctx->h_mail_tag);
-    if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
+    if (ctx->h_done) (void)hipHostFree(ctx->h_done);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1030,6 +1027,47 @@ static int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
 
 // ------------------------------------------------------------------ dimension-independent kernels
 
+// Everything a frame needs reset, in one launch (five small copies / fills of 10 us each before): node tail and
+// overflow flags, the work-queue heads of the launches the frame can have, both parities of the shadow-segment
+// counters, the reference-ray partial sums, the diagnostic words, and the primaries' range.
+__global__ void k_frame_init(Workspace ws, int n_primary, LevelRange level0, int queue_ints)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int k = i; k < queue_ints; k += stride) ws.counters[NDT_CNT_QUEUE + k] = 0;
+    for (int k = i; k < NDT_CNT_TOTAL - NDT_CNT_SEG; k += stride) ws.counters[NDT_CNT_SEG + k] = 0;
+    for (int k = i; k < 64 * 8; k += stride) ws.ref_rays[k] = 0ull;
+    for (int k = i; k < 160; k += stride) ws.dbg[k] = 0ull;
+    if (i < 4) ws.counters[i] = (i == 0) ? n_primary : 0;
+    if (i == 0) ws.levels[0] = level0;
+}
+
+// The frame's closing record, written to host-visible memory by the last kernel of the frame: the host polls its
+// tag instead of queueing three small read-backs and synchronising the stream.  One wavefront.
+//   [0] node tail  [1] overflow flags  [2] shadow slots wanted  [3] shadow rays of the frame  [4] bounces with nodes
+//   [5] rays the reference would have traced  [7] tag
+__global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, unsigned long long tag)
+{
+    const int lane = threadIdx.x;
+    unsigned long long ref = ws.ref_rays[8 * lane];         // 64 partial sums, one 64-byte line each
+    for (int d = 32; d > 0; d >>= 1) ref += __shfl_xor(ref, d, 64);
+    if (lane != 0) return;
+    long long shadow = 0;
+    int used = 0;
+    for (int b = 0; b < n_run; ++b) {
+        if (ws.levels[b].count <= 0) break;
+        shadow += ws.levels[b].n_shadow;
+        ++used;
+    }
+    done[0] = (unsigned long long)(long long)ws.counters[0];
+    done[1] = (unsigned long long)(long long)ws.counters[2];
+    done[2] = (unsigned long long)(long long)ws.counters[3];
+    done[3] = (unsigned long long)shadow;
+    done[4] = (unsigned long long)used;
+    done[5] = ref;
+    __threadfence_system();
+    __hip_atomic_store(&done[7], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // After shade_emit(level) has spawned the next bounce: publish its range, note the shadow rays
 // this bounce emitted, and clear the other parity's segment counters for the next shade_emit.
 // The range is also posted to host-visible memory: k_level_step runs early in a bounce (before
@@ -1244,14 +1282,8 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             HIP_TRY(hipEventRecord(ev_begin, s));
         }
         int *hc = ctx->h_counters;
-        hc[0] = rg.n_primary; hc[1] = 0; hc[2] = 0; hc[3] = 0;
-        HIP_TRY(hipMemcpyAsync(ws.counters, hc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(ws.ref_rays, 0, 64 * 8 * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemsetAsync(ws.dbg, 0, 160 * sizeof(unsigned long long), s));
         if (prof && getenv("NDT_HIP_EXIT_PROBE"))
             HIP_TRY(hipMemsetAsync(ws.exit_log, 0, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS * sizeof(unsigned int), s));
-        // work-queue heads of every launch of the frame + both parities of the shadow-segment counters
-        HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, (size_t)(NDT_CNT_TOTAL - NDT_CNT_QUEUE) * sizeof(int), s));
         // The stream is never synchronised inside a frame: the range of every bounce is published
         // on the device (k_level_step) and read there; the host only learns, from the mailbox,
         // whether there is a next bounce to enqueue.  Bounce 0 = the primaries.
@@ -1270,7 +1302,11 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             sh_cap = (long long)n_seg * hl[0].seg_stride;
             continue;
         }
-        HIP_TRY(hipMemcpyAsync(ws.levels, hl, sizeof(LevelRange), hipMemcpyHostToDevice, s));
+        {
+            int slots = n_levels + 2;               // one trace launch per bounce + the primaries' own
+            if (slots > NDT_QUEUE_SLOTS) slots = NDT_QUEUE_SLOTS;
+            hipLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
+        }
         int queue_slot = 0;
         int launches = 0;
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
@@ -1384,13 +1420,29 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
                            rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
-        HIP_TRY(hipMemcpyAsync(hc, ws.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
-        unsigned long long ref_rays = 0;
-        HIP_TRY(hipMemcpyAsync(ctx->h_ref, ws.ref_rays, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        if (prof) HIP_TRY(hipEventRecord(ev_end, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag);
         HIP_TRY(hipGetLastError());
+        if (prof) {
+            // the events of the profile need the stream drained anyway; the bounce table only feeds the debug output
+            if (getenv("NDT_HIP_DEBUG_LEVELS"))
+                HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(ev_end, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        {
+            // k_frame_done is the last kernel of the frame: once its tag is here, the image and the record are complete
+            const double t_wait = wall_s();
+            while (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) {
+                if (wall_s() - t_wait > 30.0) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "the frame never completed");
+                }
+            }
+        }
+        hc[0] = (int)(long long)ctx->h_done[0];
+        hc[2] = (int)(long long)ctx->h_done[1];
+        hc[3] = (int)(long long)ctx->h_done[2];
+        const unsigned long long ref_rays = ctx->h_done[5];
         if (hc[2] != 0) {
             // a pool overflowed somewhere in the frame: grow it and render again
             if (hc[2] & 1) cap *= 2;
@@ -1400,14 +1452,8 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             }
             continue;
         }
-        for (int k = 0; k < 64; ++k) ref_rays += ctx->h_ref[8 * k];
-        long long shadow_total = 0;
-        int levels_used = 0;
-        for (int b = 0; b < n_run; ++b) {
-            if (hl[b].count <= 0) break;
-            shadow_total += hl[b].n_shadow;
-            ++levels_used;
-        }
+        const long long shadow_total = (long long)ctx->h_done[3];
+        const int levels_used = (int)ctx->h_done[4];
         st = ndt_render_stats{};
         st.rays_primary = n_pixels;
         st.rays_secondary = (long long)hc[0] - rg.n_primary;
