@@ -1316,13 +1316,11 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
             tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
-                HIP_TRY(hipEventRecord(a, s));
-                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
-                HIP_TRY(hipEventRecord(b2, s));
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, a, b2);
                 trace_ev.push_back({ a, b2 });
                 trace_dbg.push_back(what);
             } else {
-                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
             }
             ++launches;
             return NDT_OK;
@@ -2230,7 +2228,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.levels = nullptr;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
-    ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words);
+    ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(obj, ws.hit_obj, cnt * sizeof(int), hipMemcpyDeviceToHost, s));

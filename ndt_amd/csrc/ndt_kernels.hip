@@ -11,6 +11,7 @@
 //   k_shade_finish second half of apply_lights (ndt.c:217-310) + the reflect / refract spawn
 //                  of get_ray_color (ndt.c:381-430)                           -> next bounce
 #include "ndt_kernels.hpp"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #ifndef NDT_DIMS
@@ -473,10 +474,25 @@ template <typename K> static int resident_blocks(K kernel, int block, size_t lds
     return per_cu * cus;
 }
 
+// ev_start / ev_stop (both or neither): HIP events that take the kernel's own dispatch timestamps
+// (hipExtLaunchKernelGGL) -- two hipEventRecord packets around the launch cost ~6 us of stream time each.
+#define NDT_LAUNCH_TRACE(kernel, grid, block, lds)                                                             \
+    do {                                                                                                       \
+        if (ev_start)                                                                                          \
+            hipExtLaunchKernelGGL((kernel), dim3((unsigned)(grid)), dim3(block), (std::uint32_t)(lds), s, ev_start, ev_stop, 0u, blob, sd, ws, job); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((kernel), dim3((unsigned)(grid)), dim3(block), lds, s, blob, sd, ws, job);      \
+    } while (0)
 static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, TraceJob job, int tier,
-                         int mask_words)
+                         int mask_words, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    if (job.count <= 0 && job.n_seg <= 0) return;
+    if (job.count <= 0 && job.n_seg <= 0) {
+        if (ev_start) {         // nothing to launch: the events still have to be valid for the caller's elapsed-time query
+            (void)hipEventRecord(ev_start, s);
+            (void)hipEventRecord(ev_stop, s);
+        }
+        return;
+    }
     static const int block = env_int("NDT_TRACE_BLOCK", NDT_TRACE_BLOCK);
     static const int force_batch = env_int("NDT_TRACE_BATCH", 0);
     job.batch = 64;
@@ -501,17 +517,17 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
             const int res = resident_blocks(k_trace<1, true, true>, lstack_block, lds_stack);
             long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
             if (nb > res) nb = res;
-            hipLaunchKernelGGL((k_trace<1, true, true>), dim3((unsigned)nb), dim3(lstack_block), lds_stack, s, blob, sd, ws, job);
+            NDT_LAUNCH_TRACE((k_trace<1, true, true>), nb, lstack_block, lds_stack);
         } else if (mask_words <= 1) {
             static int res = 0;
             if (!res) res = resident_blocks(k_trace<1, true>, block, lds);
             if (blocks > res) blocks = res;
-            hipLaunchKernelGGL((k_trace<1, true>), dim3((unsigned)blocks), dim3(block), lds, s, blob, sd, ws, job);
+            NDT_LAUNCH_TRACE((k_trace<1, true>), blocks, block, lds);
         } else {
             static int res = 0;
             if (!res) res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true>, block, lds);
             if (blocks > res) blocks = res;
-            hipLaunchKernelGGL((k_trace<NDT_MASK_REG_WORDS, true>), dim3((unsigned)blocks), dim3(block), lds, s, blob, sd, ws, job);
+            NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true>), blocks, block, lds);
         }
     } else {
         static int res = 0;
@@ -519,7 +535,7 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
         if (blocks > res) blocks = res;
         const long long max_blocks = ws.mask_slab_lanes / block;
         if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL((k_trace<0, false>), dim3((unsigned)blocks), dim3(block), 0, s, blob, sd, ws, job);
+        NDT_LAUNCH_TRACE((k_trace<0, false>), blocks, block, 0);
     }
 }
 

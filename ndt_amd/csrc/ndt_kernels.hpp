@@ -119,7 +119,9 @@ struct NdtKernelTable {
     int dims;
     void (*primary)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom);
     // tier: 0 = scene staged in LDS, visit mask in registers; 1 = scene in global memory, mask in the slab
-    void (*trace)(hipStream_t, const double *blob, SceneDesc, Workspace, TraceJob, int tier, int mask_words);
+    // ev_start / ev_stop: optional HIP events that receive the kernel's own start / stop timestamps
+    void (*trace)(hipStream_t, const double *blob, SceneDesc, Workspace, TraceJob, int tier, int mask_words, hipEvent_t ev_start,
+                  hipEvent_t ev_stop);
     // `upper` bounds the bounce's node count (sizes the grid); the range itself is ws.levels[level]
     void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
     void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
