@@ -644,31 +644,7 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
 
 // Ray (t >= 0) against the hull box of an hcube: N slabs { axis[N], centre, half extent }.
 // A miss proves that no face of the hcube can be hit (see ndt_host.hip:hcube_hull_box for the
-// margin argument), so the 2N-face scan is skipped; a pass decides nothing.
-template <int N> NDT_DEV bool hull_box_pass(const double *blob, int p, const double (&o)[N], const double (&v)[N])
-{
-    double t0 = 0.0, t1 = NDT_DBL_MAX;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double u[N];
-        blob_vec<N>(blob, p + k * (N + 2), u);
-        const double a = v_dot<N>(u, o) - blob[p + k * (N + 2) + N];
-        const double d = v_dot<N>(u, v);
-        const double h = blob[p + k * (N + 2) + N + 1];
-        if (fabs(d) < 1e-200) {
-            if (fabs(a) > h) ok = false;        // parallel to the slab and outside it
-        } else {
-            const double inv = 1.0 / d;
-            const double ta = (-h - a) * inv, tb = (h - a) * inv;
-            const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
-            if (lo > t0) t0 = lo;
-            if (hi < t1) t1 = hi;
-        }
-    }
-    return ok && t0 <= t1;
-}
-
+// margin argument), so the face scan is skipped; a pass decides nothing.
 // The hull box test plus, for hcubes that carry them (NDT_F_FACEBOX), the same test against every face's own
 // box: returns 0 when the ray misses the hull box or every face box (skip the hcube), -1 when all faces are to be
 // scanned (no face boxes), otherwise the mask of the faces whose box the ray meets (bit f = nested primitive f,
