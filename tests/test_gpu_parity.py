@@ -6,6 +6,8 @@ framebuffer.  The device uses the same IEEE +,-,*,/,sqrt sequence as the referen
 so geometry is bit-identical; only acos/cos/sin/asin/pow come from ocml instead of glibc and
 may differ in the last ulps, hence TOL_TIGHT is what we actually expect and TOL_SPEC the bar.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -273,3 +275,63 @@ def test_area_lights_make_even_one_sample_stochastic(gpu, oracle):
     from ndt_amd.hip import NdtHipError
     with pytest.raises(NdtHipError):
         gpu.render(g.width, g.height, g.depth, aa=(20, 2))
+
+
+@pytest.mark.gpu
+def test_frames_in_sequence_leave_nothing_behind(gpu, oracle):
+    """One context, frame after frame: different sizes, depths, scenes, profiled and not, host buffer and device buffer.
+    Every frame resets its own counters on the device and reports through the closing record in host-mapped memory
+    (k_frame_init / k_frame_done), so the n-th frame must come out exactly like a first one -- image and statistics."""
+    import torch
+    a, b = golden("c3_random4d"), golden("c1_hypercube3d")
+    first = {}
+    plan = [(a, 96, 54, 4, 0), (a, 40, 30, 2, 1), (b, 64, 64, 8, 0), (a, 96, 54, 4, 1), (b, 64, 64, 8, 1),
+            (a, 40, 30, 2, 0), (a, 96, 54, 1, 0), (a, 96, 54, 4, 0)]
+    for g, w, h, depth, profile in plan:
+        gpu.upload_scene(g.scene)
+        img, st = gpu.render(w, h, depth, profile=profile)
+        dev = torch.full((h, w, 4), -1.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        st_dev = gpu.render_device(dev.data_ptr(), w, h, depth, profile=profile)
+        # the call returns when the frame's closing record has arrived: the image must be complete for any other stream
+        assert np.array_equal(dev.cpu().numpy(), img)
+        key = (g.name, w, h, depth)
+        stats = (st.rays_primary, st.rays_secondary, st.rays_shadow, st.rays_ref_equiv, st.levels, st.trace_launches)
+        assert stats == (st_dev.rays_primary, st_dev.rays_secondary, st_dev.rays_shadow, st_dev.rays_ref_equiv, st_dev.levels,
+                         st_dev.trace_launches)
+        if key in first:
+            assert np.array_equal(img, first[key][0]) and stats == first[key][1], key
+        else:
+            first[key] = (img, stats)
+            want, wst = oracle.render(g.scene, w, h, depth)
+            assert np.abs(img - want).max() < 1e-9
+            assert st.rays_ref_equiv == wst.rays_ref_equiv
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads, the roofline object and (N=1) the CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--workload", "hypercube3d"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mray/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - d["rays_traced_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mray/s" and c["sample"]

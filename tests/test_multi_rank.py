@@ -72,3 +72,44 @@ def test_row_gather_single_rank_is_a_copy():
     rg = RowGather(5, 3, 4, torch.float64, "cpu", 0, 1)
     rg.local[:5] = torch.arange(60, dtype=torch.float64).reshape(5, 3, 4)
     assert torch.equal(rg.assemble(), rg.local[:5])
+
+
+def _pipelined_worker(rank, world, port, out_path):
+    """bench.py's frame loop: the gather of frame k is in flight while frame k+1 is produced into the other buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndt_amd.multi import RowGather
+    from ndt_amd import shard_rows
+    height, width, frames = 37, 5, 6
+    bufs = [RowGather(height, width, 4, torch.uint8, "cpu", rank, world, dist) for _ in range(2)]
+    n = shard_rows(height, rank, world)
+    rows = torch.arange(rank, height, world)
+    got, pending = [], None
+    for k in range(frames):
+        g = bufs[k % 2]
+        # frame k: pixel value = (row + 3 * k) mod 251, the same in every column and channel
+        g.local[:n] = ((rows + 3 * k) % 251).to(torch.uint8)[:, None, None].expand(n, width, 4)
+        if pending is not None:
+            img = pending.finish()
+            if rank == 0:
+                got.append(img.clone())
+        g.start()
+        pending = g
+    img = pending.finish()
+    if rank == 0:
+        got.append(img.clone())
+        np.save(out_path, torch.stack(got).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_one_frame_overlaps_the_next(tmp_path):
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (6, 37, 5, 4)
+    for k in range(6):
+        want = ((np.arange(37) + 3 * k) % 251).astype(np.uint8)[:, None, None] * np.ones((1, 5, 4), dtype=np.uint8)
+        assert np.array_equal(got[k], want), "frame %d" % k
