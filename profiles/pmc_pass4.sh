@@ -1,0 +1,16 @@
+#!/bin/bash
+# fourth counter family: instruction cache (is the 40 KB trace kernel served from the I-cache?) and instruction-fetch latency.
+# usage: profiles/pmc_pass4.sh <out_dir> <bench args...>
+set -u
+out=$1; shift
+mkdir -p "$out"
+export TMPDIR=/tmp
+i=0
+for set in \
+  "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" \
+  "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
+  "SQ_INSTS_BRANCH SQ_INSTS_CBRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INSTS_SALU" ; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; }
+done
+echo done
