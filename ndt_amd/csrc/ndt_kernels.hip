@@ -604,28 +604,35 @@ NDT_DEV bool light_setup(const double *blob, const SceneDesc &sd, int li, const 
     const double dotRev1 = v_dot<N>(rev_light, hit_normal);
     const double dotRev2 = v_dot<N>(rev_view, hit_normal);
     if ((dotRev1 * dotRev2) <= 0) return false;             // ndt.c:164
+    // (dist_limit / ldist2 go through two plain locals and are stored into `ss` once, below: with a store per branch the
+    // compiler merged stores to DIFFERENT fields into one store at a run-time offset, which put `ss` in scratch)
+    double dist_limit, ldist2;
+    double near_pos[N];
+    v_zero<N>(near_pos);
     if (type == NDT_LIGHT_DIRECTIONAL_) {
-        ss.dist_limit = 0.0;
-        ss.ldist2 = 1.0;
-        double near_pos[N];
+        dist_limit = 0.0;
+        ldist2 = 1.0;
         v_copy<N>(near_pos, ldir);                          // ndt.c:232-235
         v_unitize<N>(near_pos);
         v_scale<N>(near_pos, -NDT_EPS, near_pos);
         v_add<N>(near_pos, hit, near_pos);
-        v_copy<N>(shadow_o, near_pos);
         v_copy<N>(light_vec, ldir);                         // what light_vec holds after a miss, ndt.c:252
     } else {
-        ss.dist_limit = v_dist<N>(hit, lgt_pos);            // ndt.c:187-188
-        ss.dist_limit += NDT_EPS;
+        dist_limit = v_dist<N>(hit, lgt_pos);               // ndt.c:187-188
+        dist_limit += NDT_EPS;
         v_sub<N>(hit, lgt_pos, light_vec);                  // ndt.c:194-197
-        ss.ldist2 = v_dot<N>(light_vec, light_vec);
+        ldist2 = v_dot<N>(light_vec, light_vec);
         v_unitize<N>(light_vec);
         if (type == NDT_LIGHT_SPOT_) {
             const double angle = v_angle<N>(ldir, light_vec);
             if ((angle * 180.0 / NDT_PI) > blob[w + 4]) return false;     // ndt.c:204
         }
-        v_copy<N>(shadow_o, lgt_pos);
     }
+    // the origin of the shadow ray, selected by VALUE (copies from two different arrays in the two branches end in scratch)
+#pragma unroll
+    for (int c = 0; c < N; ++c) shadow_o[c] = (type == NDT_LIGHT_DIRECTIONAL_) ? near_pos[c] : lgt_pos[c];
+    ss.dist_limit = dist_limit;
+    ss.ldist2 = ldist2;
     return true;
 }
 
@@ -798,10 +805,12 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             store_soa<N>(ws.so, ws.sh_cap, slot, so);
             // point/spot: from the light along light_vec (ndt.c:211); directional: from the
             // nudged hit point along rev_light (ndt.c:238)
-            if (type == NDT_LIGHT_DIRECTIONAL_)
-                store_soa<N>(ws.sv, ws.sh_cap, slot, rev_light);
-            else
-                store_soa<N>(ws.sv, ws.sh_cap, slot, light_vec);
+            // (one store of a selected VALUE: two stores from different local arrays make the compiler pick the array
+            // through a pointer, which puts both in scratch)
+            double dir[N];
+#pragma unroll
+            for (int c = 0; c < N; ++c) dir[c] = (type == NDT_LIGHT_DIRECTIONAL_) ? rev_light[c] : light_vec[c];
+            store_soa<N>(ws.sv, ws.sh_cap, slot, dir);
             ws.slim[slot] = ss.dist_limit;
         }
         ++seg;
