@@ -222,7 +222,9 @@ int ndt_hip_upload_scene(ndt_hip_ctx *ctx, const ndt_flat_scene *scene);
 /* render_image (ndt.c:900) for the rows selected by `p`.  `rgba` receives
  * rows*width*4 doubles laid out like the reference's dbl image (image.c:126: r,g,b,a per
  * pixel, row-major).  _device: `rgba` is a device pointer on ctx's device (stays in HBM);
- * plain: `rgba` is host memory. */
+ * plain: `rgba` is host memory.  Both return when the frame is complete: every kernel of it has
+ * finished on the context's stream (the last one posts a tag to host-mapped memory the call waits for),
+ * so the image may be read from any stream or copied out at once. */
 int ndt_hip_render_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats *stats);
 int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, ndt_render_stats *stats);
 
