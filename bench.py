@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--gather", default="rgba8", choices=["f64", "rgba8"],
                     help="what the image gather moves: rgba8 = the final 8-bit image (pixel_d2c on the device, what the "
                          "reference writes to disk), f64 = the double framebuffer (8x the bytes over xGMI)")
+    ap.add_argument("--selftest-gather", action="store_true",
+                    help="--gpus 1 only: run the N>1 frame loop (double-buffered RCCL gather, events, de-interleave) in a world "
+                         "of one, to exercise that code path on a single GPU; combine with --verify")
     ap.add_argument("--verify", action="store_true",
                     help="after the run, rank 0 renders the whole frame alone and compares it with the last gathered one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -155,9 +158,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.selftest_gather        # the gather path runs
+    if multi:
         import torch.distributed as dist
-        if rehearsal:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -175,33 +183,55 @@ def main():
     gdev = "cpu" if rehearsal else "cuda"
     # Two gather buffers: the gather of frame k runs (RCCL's own stream) while frame k+1 is rendered, as an
     # animation would be produced; every frame's gather is complete before the timed region ends (fence()).
-    n_buf = 2 if world > 1 else 1
+    n_buf = 2 if multi else 1
     gdtype = torch.uint8 if args.gather == "rgba8" else torch.float64
-    gath = [RowGather(height, width, 4, gdtype, gdev, rank, world, dist) for _ in range(n_buf)]
+    gath = [RowGather(height, width, 4, gdtype, gdev, rank, world, dist, always_collective=multi) for _ in range(n_buf)]
     rows_max = gath[0].rows_max
     direct = args.gather == "f64" and not rehearsal          # render straight into the gather buffer
     frames64 = [g.local for g in gath] if direct else [torch.zeros((rows_max, width, 4), dtype=torch.float64, device="cuda")]
     stage8 = torch.zeros((rows_max, width, 4), dtype=torch.uint8, device="cuda") if (rehearsal and args.gather == "rgba8") else None
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "pending_buf": 0}
     torch.cuda.synchronize()                # the buffers above are filled on torch's stream, the renderer has its own
+
+    # GPU runs: an event per gather buffer marks "the gather that read this buffer has finished"; the host waits for it
+    # only when the buffer comes round again, two frames later, so rank 0's de-interleave (N strided copies) runs beside
+    # the next frame instead of in front of it.
+    ev_free = [torch.cuda.Event() for _ in range(n_buf)] if (multi and not rehearsal) else None
+    ev_set = [False] * n_buf
 
     def drain():
         g = state["pending"]
-        if g is not None:
+        if g is None:
+            return
+        if rehearsal:
             g.finish()
-            if not rehearsal:
-                # finish() only orders torch's stream behind the gather; the renderer writes on its own stream
-                torch.cuda.current_stream().synchronize()
-            state["pending"] = None
+        else:
+            b = state["pending_buf"]
+            g.wait()                        # torch's stream now runs behind the gather ...
+            ev_free[b].record()             # ... this marks its end ...
+            ev_set[b] = True
+            g.deinterleave()                # ... and the de-interleave follows it on that stream: the host waits for neither
+        state["pending"] = None
 
     def step(profile):
         k = state["k"]
         state["k"] = k + 1
-        g = gath[k % n_buf]
+        b = k % n_buf
+        g = gath[b]
         f64 = frames64[k % len(frames64)]
+        if direct and ev_free is not None and ev_set[b]:
+            ev_free[b].synchronize()        # --gather f64 renders straight into the gather buffer: it must be free already
+        if args.selftest_gather:
+            f64.fill_(-1.0)                 # every frame is the same image: poison what it is written into, so that a
+            torch.cuda.synchronize()        # buffer read too early or too late shows in --verify
         st = gpu.render_device(f64.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
-        if world > 1:
+        if multi:
             drain()                         # frame k-1: gathered while frame k was rendered
+            if ev_free is not None and ev_set[b]:
+                ev_free[b].synchronize()    # the gather of frame k-2 read this buffer; it ended a frame ago
+            if args.selftest_gather and args.gather == "rgba8":
+                g.local.fill_(171)
+                torch.cuda.synchronize()
             if args.gather == "rgba8":
                 dst8 = stage8 if rehearsal else g.local
                 gpu.quantize_device(f64.data_ptr(), dst8.data_ptr(), rows_max * width)
@@ -212,11 +242,12 @@ def main():
                 g.local.copy_(f64)
             g.start()
             state["pending"] = g
+            state["pending_buf"] = b
         return st
 
     def fence():
         drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -242,7 +273,7 @@ def main():
 
     counts = torch.tensor([agg["traced"], agg["ref_equiv"]], dtype=torch.float64, device=gdev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_traced, total_ref = counts.tolist()
@@ -273,7 +304,7 @@ def main():
                             "samples=1, mono, kd-tree on, specular on; rows cyclic over %d GPU(s)%s" % (
                                 cfg_idx, args.workload, fixture, dims, width, height, depth, world,
                                 ", %s gather of the %s image to rank 0" % ("RCCL" if not rehearsal else "gloo (rehearsal)", args.gather)
-                                if world > 1 else ""),
+                                if multi else ""),
                 "width": width, "height": height, "dims": dims, "max_optic_depth": depth,
                 "parallelism": "rows%d" % world,
             },
@@ -302,7 +333,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth, args.cpu_threads)
         print(json.dumps(line), flush=True)
-    if args.verify and world > 1 and rank == 0:
+    if args.verify and multi and rank == 0:
         whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")
         want = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()            # torch fills on its stream, the renderer writes on its own
@@ -321,7 +352,7 @@ def main():
         print("verify: gathered frame %s the single-GPU render" % ("==" if same else "!="), file=sys.stderr, flush=True)
         if not same:
             raise SystemExit("bench.py --verify: the gathered frame differs")
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     gpu.close()

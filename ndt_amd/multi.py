@@ -19,14 +19,17 @@ def padded_rows(height, world):
 class RowGather:
     """Pre-allocated buffers + the gather/de-interleave step for one frame geometry."""
 
-    def __init__(self, height, width, channels, dtype, device, rank, world, dist=None, dst=0):
+    def __init__(self, height, width, channels, dtype, device, rank, world, dist=None, dst=0, always_collective=False):
+        """always_collective: run the gather even in a world of one (bench.py --selftest-gather: the N>1 code path over
+        RCCL on a single GPU)."""
         self.height, self.width, self.rank, self.world, self.dist, self.dst = height, width, rank, world, dist, dst
+        self.collective = world > 1 or (always_collective and dist is not None)
         self.rows_max = padded_rows(height, world)
         self.local = torch.zeros((self.rows_max, width, channels), dtype=dtype, device=device)
         self.parts = None
         self.work = None
         self.image = None
-        if world > 1 and rank == dst:
+        if self.collective and rank == dst:
             self.parts = [torch.empty_like(self.local) for _ in range(world)]
         if rank == dst:
             self.image = torch.empty((height, width, channels), dtype=dtype, device=device)
@@ -37,23 +40,31 @@ class RowGather:
         The collective runs on the backend's own stream, so the caller may render the NEXT frame into
         ANOTHER RowGather's `local` meanwhile; this one's `local` and `parts` must stay untouched until
         `finish()` has returned and the current torch stream has been synchronised."""
-        if self.world > 1:
+        if self.collective:
             self.work = self.dist.gather(self.local, self.parts, dst=self.dst, async_op=True)
 
-    def finish(self):
-        """Wait for `start()`'s gather and de-interleave on dst; returns the frame on dst, None elsewhere."""
-        if self.world == 1:
-            self.image.copy_(self.local[:self.height])
-            return self.image
+    def wait(self):
+        """Order the current stream (gloo: the host) behind `start()`'s gather."""
         if self.work is not None:
             self.work.wait()
             self.work = None
+
+    def deinterleave(self):
+        """On dst: the gathered shards -> `image` (enqueued on the current stream); returns it, None elsewhere."""
+        if not self.collective:
+            self.image.copy_(self.local[:self.height])
+            return self.image
         if self.rank != self.dst:
             return None
         for r in range(self.world):
             n = shard_rows(self.height, r, self.world)
             self.image[r::self.world] = self.parts[r][:n]
         return self.image
+
+    def finish(self):
+        """Wait for `start()`'s gather and de-interleave on dst; returns the frame on dst, None elsewhere."""
+        self.wait()
+        return self.deinterleave()
 
     def assemble(self):
         """Gather every rank's `local` rows to `dst` and de-interleave; returns the frame on dst."""

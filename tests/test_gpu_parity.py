@@ -335,3 +335,23 @@ def test_bench_line_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mray/s" and c["sample"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["rgba8", "f64"])
+def test_bench_gather_loop_over_rccl_in_a_world_of_one(fmt):
+    """bench.py's N>1 frame loop -- double-buffered asynchronous RCCL gather, the events that free a buffer, rank 0's
+    de-interleave beside the next frame -- run through RCCL in a world of one, frame and gather buffers poisoned before
+    every frame, the last gathered frame compared byte for byte with a plain render (--verify)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--workload",
+           "hypercube3d", "--no-cpu-baseline", "--selftest-gather", "--verify", "--gather", fmt]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "verify: gathered frame == the single-GPU render" in out.stderr
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
