@@ -136,7 +136,8 @@ def main():
                          "reference writes to disk), f64 = the double framebuffer (8x the bytes over xGMI)")
     ap.add_argument("--selftest-gather", action="store_true",
                     help="--gpus 1 only: run the N>1 frame loop (double-buffered RCCL gather, events, de-interleave) in a world "
-                         "of one, to exercise that code path on a single GPU; combine with --verify")
+                         "of one, to exercise that code path on a single GPU; with --verify the frame and gather buffers "
+                         "are poisoned before every frame and the last gathered frame is checked")
     ap.add_argument("--verify", action="store_true",
                     help="after the run, rank 0 renders the whole frame alone and compares it with the last gathered one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -197,6 +198,8 @@ def main():
     # only when the buffer comes round again, two frames later, so rank 0's de-interleave (N strided copies) runs beside
     # the next frame instead of in front of it.
     ev_free = [torch.cuda.Event() for _ in range(n_buf)] if (multi and not rehearsal) else None
+    # the renderer's stream as torch sees it: the gather is ordered behind the quantisation without stopping the host
+    ctx_stream = torch.cuda.ExternalStream(gpu.stream) if (multi and not rehearsal) else None
     ev_set = [False] * n_buf
 
     def drain():
@@ -221,7 +224,7 @@ def main():
         f64 = frames64[k % len(frames64)]
         if direct and ev_free is not None and ev_set[b]:
             ev_free[b].synchronize()        # --gather f64 renders straight into the gather buffer: it must be free already
-        if args.selftest_gather:
+        if args.selftest_gather and args.verify:
             f64.fill_(-1.0)                 # every frame is the same image: poison what it is written into, so that a
             torch.cuda.synchronize()        # buffer read too early or too late shows in --verify
         st = gpu.render_device(f64.data_ptr(), width, height, depth, row_begin=rank, row_step=world, profile=profile)
@@ -229,13 +232,16 @@ def main():
             drain()                         # frame k-1: gathered while frame k was rendered
             if ev_free is not None and ev_set[b]:
                 ev_free[b].synchronize()    # the gather of frame k-2 read this buffer; it ended a frame ago
-            if args.selftest_gather and args.gather == "rgba8":
+            if args.selftest_gather and args.verify and args.gather == "rgba8":
                 g.local.fill_(171)
                 torch.cuda.synchronize()
             if args.gather == "rgba8":
                 dst8 = stage8 if rehearsal else g.local
                 gpu.quantize_device(f64.data_ptr(), dst8.data_ptr(), rows_max * width)
-                gpu.synchronize()
+                if ctx_stream is not None:
+                    torch.cuda.current_stream().wait_stream(ctx_stream)
+                else:
+                    gpu.synchronize()
                 if rehearsal:
                     g.local.copy_(stage8)
             elif rehearsal:

@@ -30,8 +30,13 @@ class RowGather:
         self.work = None
         self.image = None
         if self.collective and rank == dst:
-            self.parts = [torch.empty_like(self.local) for _ in range(world)]
-        if rank == dst:
+            # one buffer for all shards and an image padded to world * rows_max rows: the de-interleave is then ONE strided
+            # copy (shard r, row i -> image row i*world + r; the padding rows of a ragged split land behind the image)
+            self._shards = torch.empty((world, self.rows_max, width, channels), dtype=dtype, device=device)
+            self.parts = [self._shards[r] for r in range(world)]
+            self._padded = torch.empty((self.rows_max * world, width, channels), dtype=dtype, device=device)
+            self.image = self._padded[:height]
+        elif rank == dst:
             self.image = torch.empty((height, width, channels), dtype=dtype, device=device)
 
     def start(self):
@@ -56,9 +61,7 @@ class RowGather:
             return self.image
         if self.rank != self.dst:
             return None
-        for r in range(self.world):
-            n = shard_rows(self.height, r, self.world)
-            self.image[r::self.world] = self.parts[r][:n]
+        self._padded.view(self.rows_max, self.world, self.width, -1).copy_(self._shards.permute(1, 0, 2, 3))
         return self.image
 
     def finish(self):
