@@ -8,6 +8,7 @@
 // There is no CPU fallback here: without a usable HIP device every entry point fails with
 // NDT_E_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1277,9 +1278,9 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
         std::vector<std::string> trace_dbg;
         if (prof) {
+            // frame time = start of the frame's first kernel .. end of its last (their own dispatch timestamps)
             ev_begin = get_event(ctx, ev_n++);
             ev_end = get_event(ctx, ev_n++);
-            HIP_TRY(hipEventRecord(ev_begin, s));
         }
         int *hc = ctx->h_counters;
         if (prof && getenv("NDT_HIP_EXIT_PROBE"))
@@ -1305,7 +1306,10 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         {
             int slots = n_levels + 2;               // one trace launch per bounce + the primaries' own
             if (slots > NDT_QUEUE_SLOTS) slots = NDT_QUEUE_SLOTS;
-            hipLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
+            if (prof)
+                hipExtLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
+            else
+                hipLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
         }
         int queue_slot = 0;
         int launches = 0;
@@ -1418,13 +1422,14 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
                            rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
-        hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag);
+        if (prof)
+            hipExtLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, n_run, ctx->d_done, tag);
+        else
+            hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag);
         HIP_TRY(hipGetLastError());
-        if (prof) {
-            // the events of the profile need the stream drained anyway; the bounce table only feeds the debug output
-            if (getenv("NDT_HIP_DEBUG_LEVELS"))
-                HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipEventRecord(ev_end, s));
+        if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
+            // the bounce table only feeds the debug output
+            HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         {
@@ -1437,6 +1442,7 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                 }
             }
         }
+        if (prof) HIP_TRY(hipEventSynchronize(ev_end));     // the closing kernel has run: its completion is at most microseconds away
         hc[0] = (int)(long long)ctx->h_done[0];
         hc[2] = (int)(long long)ctx->h_done[1];
         hc[3] = (int)(long long)ctx->h_done[2];
