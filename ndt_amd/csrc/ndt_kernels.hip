@@ -636,8 +636,19 @@ NDT_DEV bool light_setup(const double *blob, const SceneDesc &sd, int li, const 
     return true;
 }
 
+// What the wavefronts of one shade_emit workgroup reserve together: every wavefront adds its wants here (LDS atomics,
+// which also hand it its offset inside the workgroup's share), ONE wavefront turns the sums into global reservations, and
+// the bases come back through LDS.  A global counter takes ~150 returning atomics per us; with a reservation per wavefront
+// the 32 k wavefronts of a frame whose primaries all hit something queued on two counters for 320 us (the whole
+// shade_emit(0) of the 3-D scene), each wavefront alive for 40 us waiting its turn.
+struct EmitShared {
+    int spawn_total, spawn_base;
+    int seg_total[64], seg_base[64];
+};
+
+// (every thread of the workgroup calls this: it holds two workgroup barriers)
 NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
-                             const LevelRange &lr, int level, long long r)
+                             const LevelRange &lr, int level, long long r, EmitShared *sh)
 {
     const bool in_range = r < lr.count;
     const long long g = lr.begin + (in_range ? r : 0);
@@ -672,9 +683,9 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             ws.count[g] = 1;
         }
     }
-    // a wavefront of background only (two thirds of the primaries' wavefronts on the benchmark frame) is done here:
-    // no light fires, nothing spawns, and every collective below would come out empty
-    if (__ballot(shaded) == 0ull) return;
+    // a wavefront of background only (two thirds of the primaries' wavefronts on the benchmark frame) skips the work
+    // below -- no light fires, nothing spawns, every collective would come out empty -- but not the workgroup's barriers
+    const bool live = __ballot(shaded) != 0ull;
     // One shadow ray per light that passes the same-side / cone tests.  The queue is segmented
     // by light: the rays a wavefront later traces then share their origin (the light) and aim
     // at neighbouring hit points, instead of interleaving five unrelated origins.  Within a
@@ -696,14 +707,14 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     NDT_SEC(1);
     // lane s learns how many lanes fire segment s's light, and which light that is
     int my_total = 0, seg = 0;
-    for (int li = 0; li < sd.n_lights; ++li) {
-        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;     // wave-uniform
-        const unsigned long long vote = __ballot((fire >> li) & 1ull);
-        if (lane == seg) my_total = __popcll(vote);
-        ++seg;
+    if (live) {
+        for (int li = 0; li < sd.n_lights; ++li) {
+            if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;     // wave-uniform
+            const unsigned long long vote = __ballot((fire >> li) & 1ull);
+            if (lane == seg) my_total = __popcll(vote);
+            ++seg;
+        }
     }
-    int my_base = 0;
-    if (my_total > 0) my_base = atomicAdd(&NDT_SEG_COUNTERS(ws, level)[lane], my_total);
     if (shaded) ws.sh_mask[g] = fire;
     NDT_SEC(2);
     // get_ray_color, ndt.c:381-430: spawn reflection / refraction.  The children depend on the
@@ -752,7 +763,19 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     // wavefront, reflection rays first and refraction rays after them.
     const unsigned long long v_refl = __ballot(want_refl), v_refr = __ballot(want_refr);
     const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
-    const int base = wave_reserve(&ws.counters[0], total);
+    // the workgroup's reservations: wants in, one wavefront asks the global counters, bases out
+    int my_off = 0, wave_off = 0;
+    if (my_total > 0) my_off = atomicAdd(&sh->seg_total[lane], my_total);
+    if (lane == 0 && total > 0) wave_off = atomicAdd(&sh->spawn_total, total);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int want = sh->seg_total[threadIdx.x];
+        if (want > 0) sh->seg_base[threadIdx.x] = atomicAdd(&NDT_SEG_COUNTERS(ws, level)[threadIdx.x], want);
+        if (threadIdx.x == 0 && sh->spawn_total > 0) sh->spawn_base = atomicAdd(&ws.counters[0], sh->spawn_total);
+    }
+    __syncthreads();
+    const int my_base = (my_total > 0) ? sh->seg_base[lane] + my_off : 0;
+    const int base = (total > 0) ? sh->spawn_base + __shfl(wave_off, 0, 64) : 0;
     if (total > 0 && (long long)base + total > ws.cap) {
         // node pool overflow: flag it (the host renders the frame again with a larger pool), spawn nothing
         if (lane == 0) atomicOr(&ws.counters[2], 1);
@@ -787,9 +810,9 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
         ws.child_refr[g] = (int)c;
     }
     NDT_SEC(3);
-    // shadow rays into their segments (the reservation above has had the whole spawn section to come back)
+    // shadow rays into their segments
     seg = 0;
-    for (int li = 0; li < sd.n_lights; ++li) {
+    for (int li = 0; live && li < sd.n_lights; ++li) {
         if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
         const bool fires = (fire >> li) & 1ull;
         const unsigned long long vote = __ballot(fires);
@@ -838,11 +861,15 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
 // half the occupancy.)
 __global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
 {
+    __shared__ EmitShared sh;
     const LevelRange lr = ws.levels[level];
     const long long base = (long long)blockIdx.x * blockDim.x;
     if (base < lr.count) {
         NDT_SHADE_LOG_BEGIN();
-        shade_emit_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+        if (threadIdx.x < 64) sh.seg_total[threadIdx.x] = 0;
+        if (threadIdx.x == 0) sh.spawn_total = 0;
+        __syncthreads();
+        shade_emit_node(blob, sd, ws, rg, lr, level, base + threadIdx.x, &sh);
         NDT_SHADE_LOG_END();
     }
 }
@@ -959,6 +986,7 @@ __global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, Sce
 __global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
                                                        unsigned n_finish)
 {
+    __shared__ EmitShared sh;
     if (blockIdx.x < n_finish) {
         const LevelRange lr = ws.levels[level];
         const long long base = (long long)blockIdx.x * blockDim.x;
@@ -972,7 +1000,10 @@ __global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, Scene
         const long long base = (long long)(blockIdx.x - n_finish) * blockDim.x;
         if (base < lr.count) {
             NDT_SHADE_LOG_BEGIN();
-            shade_emit_node(blob, sd, ws, rg, lr, level + 1, base + threadIdx.x);
+            if (threadIdx.x < 64) sh.seg_total[threadIdx.x] = 0;
+            if (threadIdx.x == 0) sh.spawn_total = 0;
+            __syncthreads();
+            shade_emit_node(blob, sd, ws, rg, lr, level + 1, base + threadIdx.x, &sh);
             NDT_SHADE_LOG_END();
         }
     }
