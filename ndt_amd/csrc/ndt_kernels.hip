@@ -301,42 +301,39 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     }
     const long long dense_batches = (dense_count + bs - 1) >> sh;
     const long long n_batches = dense_batches + seg_batches;
-    // Logical batch order: the dense part (closest-hit rays, the expensive ones) first, the
-    // shadow segments after it.  Logical batch L belongs to queue shard L % SHARDS, so every
-    // shard starts with expensive batches and ends with cheap ones: what is still running when
-    // the queue drains -- the tail every launch pays for -- is a cheap batch.
-    // Each shard has its own head on its own cache line (a single head word saturates near
-    // 90 pops/us on MI355X).  A wavefront drains its home shard (workgroup id mod shards, i.e. the
-    // workgroups that share an XCD) and then steals from the others; it exits when every shard
-    // is empty.  (Handing out several batches per pop was measured: the heads get cheaper, the
-    // tail gets longer, and the launch slower.)
-    int shard_try = 0;
-    const int home = blockIdx.x % NDT_QUEUE_SHARDS;
-    unsigned live_shards = (1u << NDT_QUEUE_SHARDS) - 1u;       // shards that may still hold batches (bit = shard index)
+    // Logical batch order: the dense part (closest-hit rays) first, the shadow segments after it.  Logical batch L
+    // belongs to queue shard L % SHARDS; each shard has its own head on its own cache line (one head word serves
+    // ~150 returning atomics per us).  A wavefront draws from its home shard (workgroup id mod shards) first.
+    // (Handing out several batches per pop was measured: the heads get cheaper, the tail gets longer, and the
+    // launch slower.  8 shards -- one per XCD -- against 64: the 3-D scene, whose batches are short, 0.83 -> 0.63 ms
+    // a frame, C3 1.67 -> 1.62.)
+    // When the shard a wavefront draws from is drained it reads every head once (lane i reads head i: one round
+    // trip) and moves straight to the next shard that still holds batches; it exits when none does.  (With one
+    // probing atomic per drained shard the end of a launch cost up to shards - 1 round trips per wavefront.)
+    int cur = blockIdx.x % NDT_QUEUE_SHARDS;                    // home shard
+    bool any_left = true;
     while (true) {
         long long b = -1;           // logical batch
-        while (shard_try < NDT_QUEUE_SHARDS) {
-            const int sh_i = (home + shard_try) % NDT_QUEUE_SHARDS;
-            const long long n_here = (n_batches - sh_i + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
+        while (any_left) {
+            const long long n_here = (n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
             int k = 0;
-            const bool may = n_here > 0 && ((live_shards >> sh_i) & 1u);
-            if (may) {
-                if (lane == 0) k = atomicAdd(job.queue + sh_i * NDT_QUEUE_STRIDE, 1);
-                k = __shfl(k, 0, 64);
-            }
-            if (may && k < n_here) {
-                b = (long long)k * NDT_QUEUE_SHARDS + sh_i;
+            if (lane == 0) k = atomicAdd(job.queue + cur * NDT_QUEUE_STRIDE, 1);
+            k = __shfl(k, 0, 64);
+            if (k < n_here) {
+                b = (long long)k * NDT_QUEUE_SHARDS + cur;
                 break;
             }
-            ++shard_try;       // this shard is drained for good
-            if (shard_try == 1) {
-                // home shard empty: look at all the other heads in ONE round trip (lane i reads head i) before
-                // trying them one atomic at a time -- at the end of a launch they are all drained
-                int head = 0x7fffffff;
-                if (lane < NDT_QUEUE_SHARDS)
-                    head = __hip_atomic_load(job.queue + lane * NDT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long mine = (n_batches - lane + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
-                live_shards = (unsigned)__ballot(lane < NDT_QUEUE_SHARDS && (long long)head < mine);
+            int head = 0x7fffffff;
+            if (lane < NDT_QUEUE_SHARDS)
+                head = __hip_atomic_load(job.queue + lane * NDT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long mine = (n_batches - lane + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+            const unsigned long long live = __ballot(lane < NDT_QUEUE_SHARDS && (long long)head < mine);
+            if (live == 0ull) {
+                any_left = false;
+            } else {
+                // the next live shard after `cur`, cyclically
+                const unsigned long long above = (cur + 1 < 64) ? (live >> (cur + 1)) << (cur + 1) : 0ull;
+                cur = __ffsll((long long)(above ? above : live)) - 1;
             }
         }
         if (b < 0) break;

@@ -145,7 +145,9 @@ extern "C" const NdtKernelTable *ndt_kernel_table_8();
 #define NDT_TRACE_MAX_BLOCK 768
 #endif
 #define NDT_QUEUE_SLOTS 512                 /* trace launches per render call that get a work queue */
-#define NDT_QUEUE_SHARDS 8                  /* queue heads per launch (one per XCD-sized group of workgroups) */
+#ifndef NDT_QUEUE_SHARDS
+#define NDT_QUEUE_SHARDS 64                 /* queue heads per launch (one lane reads one head); with 8 -- one per XCD -- 384 wavefronts shared a head */
+#endif
 #define NDT_QUEUE_STRIDE 16                 /* ints between heads: one 64-byte line each */
 #define NDT_QUEUE_INTS (NDT_QUEUE_SHARDS * NDT_QUEUE_STRIDE)
 #define NDT_CNT_QUEUE 16
