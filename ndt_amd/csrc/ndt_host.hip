@@ -1614,6 +1614,20 @@ struct AaTask {
     int _pad;
 };
 
+// One slot of a device-side list for every lane that wants one, with ONE atomic per wavefront (a counter serves ~150
+// returning atomics per us: a list appended to by every thread of a 2-million-thread launch queues for milliseconds).
+// Every lane of the wavefront has to call it.
+__device__ __forceinline__ int wave_append(int *counter, bool want)
+{
+    const unsigned long long vote = __ballot(want);
+    if (vote == 0ull) return 0;
+    const int lane = __lane_id(), leader = __ffsll((long long)vote) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(vote));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(vote & ((1ull << lane) - 1ull));
+}
+
 __device__ __forceinline__ void aa_avg4(const double *p1, const double *p2, const double *p3, const double *p4, double *avg, double *var)
 {
     for (int c = 0; c < 4; ++c) avg[c] = (p1[c] + p2[c] + p3[c] + p4[c]) / 4;
@@ -1629,8 +1643,9 @@ __device__ __forceinline__ void aa_avg4(const double *p1, const double *p2, cons
 __global__ void k_aa_seed(const double *pass1, int width, int rows, int row_begin, int row_step, int row_pair, double threshold,
                           double *out, AaTask *tasks, int *counter)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)rows * width) return;
+    const long long idx_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx_raw < (long long)rows * width;
+    const long long idx = in_range ? idx_raw : 0;
     const int l = (int)(idx / width), i = (int)(idx % width);
     const int r0 = row_pair ? 2 * l : l, r1 = r0 + 1;
     const long long w1 = width + 1;
@@ -1638,8 +1653,10 @@ __global__ void k_aa_seed(const double *pass1, int width, int rows, int row_begi
     const double *p3 = pass1 + (r1 * w1 + i) * 4, *p4 = p3 + 4;
     double clr[4], var = 0.0;
     aa_avg4(p1, p2, p3, p4, clr, &var);
-    if (var > threshold) {
-        const int t = atomicAdd(counter, 1);
+    const bool refine = in_range && var > threshold;
+    const int t = wave_append(counter, refine);
+    if (!in_range) return;
+    if (refine) {
         AaTask &T = tasks[t];
         T.x = i;
         T.y = row_begin + l * row_step;
@@ -1669,8 +1686,9 @@ __global__ void k_aa_samples(const AaTask *tasks, int n_tasks, double step, doub
 __global__ void k_aa_split(AaTask *tasks, int n_tasks, double step, double threshold, const double *colours,
                            AaTask *next, int *next_counter)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tasks) return;
+    const int t_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = t_raw < n_tasks;
+    const int t = in_range ? t_raw : 0;          // (lanes past the end go through the motions on task 0 and write nothing)
     AaTask &T = tasks[t];
     const double *p5 = colours + (long long)t * 20, *p6 = p5 + 4, *p7 = p5 + 8, *p8 = p5 + 12, *p9 = p5 + 16;
     const double hs = step / 2;
@@ -1680,10 +1698,13 @@ __global__ void k_aa_split(AaTask *tasks, int n_tasks, double step, double thres
     const double *qc[4][4] = { { T.p[0], p6, p7, p5 }, { p6, T.p[1], p5, p8 }, { p7, p5, T.p[2], p9 }, { p5, p8, p9, T.p[3] } };
     const double qx[4] = { T.x, T.x + hs, T.x, T.x + hs }, qy[4] = { T.y, T.y, T.y + hs, T.y + hs };
     for (int k = 0; k < 4; ++k) {
-        double var = 0.0;
-        aa_avg4(qa[k][0], qa[k][1], qa[k][2], qa[k][3], T.sp[k], &var);
-        if (var > threshold) {
-            const int c = atomicAdd(next_counter, 1);
+        double var = 0.0, avg[4];
+        aa_avg4(qa[k][0], qa[k][1], qa[k][2], qa[k][3], avg, &var);
+        if (in_range)
+            for (int ch = 0; ch < 4; ++ch) T.sp[k][ch] = avg[ch];
+        const bool refine = in_range && var > threshold;
+        const int c = wave_append(next_counter, refine);
+        if (refine) {
             AaTask &C = next[c];
             C.x = qx[k];
             C.y = qy[k];
@@ -1912,11 +1933,11 @@ __global__ void k_ns_accumulate(const int *active, int n_active, int per, const 
                                 double *acc, int *taken, int *next, int *next_count)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_active) return;
-    const int pix = active[a];
+    const bool in_range = a < n_active;
+    const int pix = in_range ? active[a] : 0;
     double *t = acc + 5ll * pix;            // t_clr rgba + clr_diff
-    double clr_diff = t[4];
-    bool go_on = true;
+    double clr_diff = in_range ? t[4] : 0.0;
+    bool go_on = in_range;
     int used = 0;
     for (int r = 0; r < per && go_on; ++r) {
         const double *l = colours + 4ll * ((long long)a * per + r);
@@ -1933,9 +1954,12 @@ __global__ void k_ns_accumulate(const int *active, int n_active, int per, const 
         const int done = i + 1;
         go_on = done < min_samples || (done < 10000 && clr_diff > 1.0 / 256.0);
     }
-    t[4] = clr_diff;
-    taken[pix] += used;
-    if (go_on) next[atomicAdd(next_count, 1)] = pix;
+    if (in_range) {
+        t[4] = clr_diff;
+        taken[pix] += used;
+    }
+    const int slot = wave_append(next_count, go_on);
+    if (go_on) next[slot] = pix;
 }
 
 __global__ void k_ns_init(double *acc, int *active, int *taken, long long n_pixels)
