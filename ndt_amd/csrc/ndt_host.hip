@@ -1266,6 +1266,11 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
     if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
     const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
     if (sh_cap < want_sh) sh_cap = want_sh;
+    if (getenv("NDT_HIP_TEST_SMALL_POOL") && ctx->ws.cap == 0) {
+        // tests only: a fresh context starts with a node pool that a reflective scene overflows, so that the
+        // overflow -> grow -> render-again path below is exercised (tests/test_gpu_parity.py)
+        cap = ((n_primary + 63) & ~63LL) + 64;
+    }
 
     const NdtKernelTable *kt = ctx->kt;
     for (int attempt = 0; attempt < 8; ++attempt) {

@@ -355,3 +355,32 @@ def test_bench_gather_loop_over_rccl_in_a_world_of_one(fmt):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "verify: gathered frame == the single-GPU render" in out.stderr
     assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
+
+
+@pytest.mark.gpu
+def test_node_pool_overflow_renders_again():
+    """A frame whose ray tree does not fit the node pool flags it on the device (the frame's closing record carries the
+    flag), the host doubles the pool and renders the frame again: same image, same counts, larger pool."""
+    from ndt_amd.hip import NdtHip
+    g = golden("c1_hypercube3d")            # mirrors: about two secondary rays for every three primaries
+    ref = NdtHip(0)
+    try:
+        ref.upload_scene(g.scene)
+        want, wst = ref.render(g.width, g.height, g.depth)
+    finally:
+        ref.close()
+    os.environ["NDT_HIP_TEST_SMALL_POOL"] = "1"
+    small = NdtHip(0)
+    try:
+        small.upload_scene(g.scene)
+        got, st = small.render(g.width, g.height, g.depth)
+        again, st2 = small.render(g.width, g.height, g.depth)
+    finally:
+        del os.environ["NDT_HIP_TEST_SMALL_POOL"]
+        small.close()
+    assert wst.rays_secondary > 256                         # the small pool (primaries + 64 nodes) cannot hold them
+    assert np.array_equal(got, want) and np.array_equal(again, want)
+    for a in (st, st2):
+        assert (a.rays_primary, a.rays_secondary, a.rays_shadow, a.rays_ref_equiv) == \
+               (wst.rays_primary, wst.rays_secondary, wst.rays_shadow, wst.rays_ref_equiv)
+    assert st.node_capacity >= wst.rays_primary + wst.rays_secondary
