@@ -515,6 +515,12 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
             long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
             if (nb > res) nb = res;
             NDT_LAUNCH_TRACE((k_trace<1, true, true>), nb, lstack_block, lds_stack);
+        } else if (lstack_block >= 64 && mask_words > 1 && lds_stack <= 160 * 1024) {
+            // scenes of 65 .. 256 objects (a register mask of four words): the same, with the wider mask
+            const int res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true, true>, lstack_block, lds_stack);
+            long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
+            if (nb > res) nb = res;
+            NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true, true>), nb, lstack_block, lds_stack);
         } else if (mask_words <= 1) {
             static int res = 0;
             if (!res) res = resident_blocks(k_trace<1, true>, block, lds);
