@@ -310,30 +310,48 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     // When the shard a wavefront draws from is drained it reads every head once (lane i reads head i: one round
     // trip) and moves straight to the next shard that still holds batches; it exits when none does.  (With one
     // probing atomic per drained shard the end of a launch cost up to shards - 1 round trips per wavefront.)
+    // The end of a launch: a wavefront cannot move to another SIMD, so when the queue runs dry the SIMDs whose three
+    // wavefronts each took one of the last batches run them three to a SIMD -- three batch times -- while most of the
+    // chip idles (that, not the content of the batches, is the tail of a launch: exact longest-first order did not
+    // shorten it).  So the last `tail_solo` batches of every shard are left to ONE wavefront per SIMD (workgroup
+    // wavefronts w, w+4, w+8 share a SIMD: the ones with w >= 4 stay away from them and leave early).
+    const int reserve = ((threadIdx.x >> 6) >= 4) ? job.tail_solo : 0;
     int cur = blockIdx.x % NDT_QUEUE_SHARDS;                    // home shard
+    long long last_k = -1;                                      // this wavefront's last pop from `cur`
     bool any_left = true;
     while (true) {
         long long b = -1;           // logical batch
         while (any_left) {
             const long long n_here = (n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
-            int k = 0;
-            if (lane == 0) k = atomicAdd(job.queue + cur * NDT_QUEUE_STRIDE, 1);
-            k = __shfl(k, 0, 64);
-            if (k < n_here) {
-                b = (long long)k * NDT_QUEUE_SHARDS + cur;
-                break;
+            bool may = true;
+            if (reserve > 0 && last_k + 1 + 4 * reserve >= n_here) {
+                // near the shard's end: look before taking (what is taken cannot be given back)
+                const int head_cur = __hip_atomic_load(job.queue + cur * NDT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                may = (long long)head_cur < n_here - reserve;
+            }
+            if (may) {
+                int k = 0;
+                if (lane == 0) k = atomicAdd(job.queue + cur * NDT_QUEUE_STRIDE, 1);
+                k = __shfl(k, 0, 64);
+                if (k < n_here) {
+                    b = (long long)k * NDT_QUEUE_SHARDS + cur;
+                    last_k = k;
+                    break;
+                }
             }
             int head = 0x7fffffff;
             if (lane < NDT_QUEUE_SHARDS)
                 head = __hip_atomic_load(job.queue + lane * NDT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long mine = (n_batches - lane + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+            const long long mine = (n_batches - lane + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS - reserve;
             const unsigned long long live = __ballot(lane < NDT_QUEUE_SHARDS && (long long)head < mine);
+
             if (live == 0ull) {
                 any_left = false;
             } else {
                 // the next live shard after `cur`, cyclically
                 const unsigned long long above = (cur + 1 < 64) ? (live >> (cur + 1)) << (cur + 1) : 0ull;
                 cur = __ffsll((long long)(above ? above : live)) - 1;
+                last_k = (long long)__shfl(head, cur, 64) - 1;      // where that shard's head stood a moment ago
             }
         }
         if (b < 0) break;
@@ -494,6 +512,10 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
     static const int force_batch = env_int("NDT_TRACE_BATCH", 0);
     job.batch = 64;
     job.skip_trace = env_int("NDT_TRACE_SKIP", 0);
+    {
+        static const int tail_solo = env_int("NDT_TRACE_TAIL_SOLO", 16);
+        job.tail_solo = tail_solo > 0 ? tail_solo : 0;
+    }
     if (force_batch == 64 || force_batch == 32 || force_batch == 16 || force_batch == 8) job.batch = force_batch;
     const long long upper = job.count + (job.n_seg > 0 ? job.seg_stride * job.n_seg : 0);      // sizes the grid only
     long long blocks = (upper + job.batch * (block / 64) - 1) / (job.batch * (block / 64));

@@ -107,6 +107,7 @@ struct TraceJob {
     int *queue;                 // device-side work-queue heads for this launch (zeroed by the host)
     int batch;                  // rays per wavefront batch: 64, 32, 16 or 8 (set by the launcher)
     int skip_trace;             // diagnostic build only: pop, load and store but do not traverse
+    int tail_solo;              // the last this-many batches of every queue shard go to one wavefront per SIMD only (k_trace)
     unsigned int *exit_log;     // NDT_HIP_EXIT_PROBE: {start, start of the last batch, exit} per wavefront (100 MHz clock, low words)
 };
 #define NDT_EXIT_LOG_WORDS 12288    /* per launch: 3 words x 4096 wavefronts */
