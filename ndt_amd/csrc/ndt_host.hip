@@ -1532,21 +1532,23 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                             const unsigned int *q = log.data() + (size_t)l * NDT_EXIT_LOG_WORDS;
                             unsigned int t0 = 0;
                             int n_w = 0;
-                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 3; ++w)
-                                if (q[3 * w + 2]) {
-                                    if (!n_w || (int)(q[3 * w] - t0) < 0) t0 = q[3 * w];
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
+                                if (q[4 * w + 2]) {
+                                    if (!n_w || (int)(q[4 * w] - t0) < 0) t0 = q[4 * w];
                                     ++n_w;
                                 }
                             int hist[64] = { 0 };
                             double first = 1e30, last = 0, last_batch = 0, start_spread = 0;
-                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 3; ++w)
-                                if (q[3 * w + 2]) {
-                                    const double st_us = (q[3 * w] - t0) / 100.0, ex_us = (q[3 * w + 2] - t0) / 100.0;
+                            int simd_of_wave[12][4] = { { 0 } };        // workgroup wavefront w (768-lane workgroups) -> SIMD it ran on
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
+                                if (q[4 * w + 2]) {
+                                    const double st_us = (q[4 * w] - t0) / 100.0, ex_us = (q[4 * w + 2] - t0) / 100.0;
+                                    ++simd_of_wave[w % 12][(q[4 * w + 3] >> 4) & 3];
                                     if (st_us > start_spread) start_spread = st_us;
                                     if (ex_us < first) first = ex_us;
                                     if (ex_us > last) {
                                         last = ex_us;
-                                        last_batch = (q[3 * w + 2] - q[3 * w + 1]) / 100.0;
+                                        last_batch = (q[4 * w + 2] - q[4 * w + 1]) / 100.0;
                                     }
                                     const int bin = (int)(ex_us / 16.0);
                                     ++hist[bin > 63 ? 63 : bin];
@@ -1558,6 +1560,15 @@ static int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba,
                                     snprintf(buf, sizeof buf, " %d-%d:%d", bin * 16, bin * 16 + 16, hist[bin]);
                                     line += buf;
                                 }
+                            if (l == 0) {
+                                std::string m;
+                                for (int w = 0; w < 12; ++w) {
+                                    char buf[64];
+                                    snprintf(buf, sizeof buf, " w%d:%d/%d/%d/%d", w, simd_of_wave[w][0], simd_of_wave[w][1], simd_of_wave[w][2], simd_of_wave[w][3]);
+                                    m += buf;
+                                }
+                                fprintf(stderr, "ndt_hip: SIMD 0/1/2/3 of the workgroup's wavefronts (768-lane workgroups):%s\n", m.c_str());
+                            }
                             fprintf(stderr, "ndt_hip: trace launch %d: %d wavefronts start within %.1f us; first out of work at %.1f us, last at %.1f us (its last batch: %.1f us); exits per 16 us:%s\n",
                                     l, n_w, start_spread, first, last, last_batch, line.c_str());
                         }

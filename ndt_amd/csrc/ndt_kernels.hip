@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     // wavefronts each took one of the last batches run them three to a SIMD -- three batch times -- while most of the
     // chip idles (that, not the content of the batches, is the tail of a launch: exact longest-first order did not
     // shorten it).  So the last `tail_solo` batches of every shard are left to ONE wavefront per SIMD (workgroup
-    // wavefronts w, w+4, w+8 share a SIMD: the ones with w >= 4 stay away from them and leave early).
+    // wavefronts w, w+4, w+8 share a SIMD -- NDT_HIP_EXIT_PROBE prints the HW_ID census that shows it: the ones with
+    // w >= 4 stay away from them and leave early).
     const int reserve = ((threadIdx.x >> 6) >= 4) ? job.tail_solo : 0;
     int cur = blockIdx.x % NDT_QUEUE_SHARDS;                    // home shard
     long long last_k = -1;                                      // this wavefront's last pop from `cur`
@@ -447,10 +448,11 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     if (job.exit_log && lane == 0) {
         // one private slot per wavefront: shared counters would serialise the very exits they measure
         const unsigned int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-        if (3 * w + 2 < NDT_EXIT_LOG_WORDS) {
-            job.exit_log[3 * w] = probe_start;
-            job.exit_log[3 * w + 1] = probe_batch;
-            job.exit_log[3 * w + 2] = (unsigned int)wall_clock64() | 1u;
+        if (4 * w + 3 < NDT_EXIT_LOG_WORDS) {
+            job.exit_log[4 * w] = probe_start;
+            job.exit_log[4 * w + 1] = probe_batch;
+            job.exit_log[4 * w + 2] = (unsigned int)wall_clock64() | 1u;
+            job.exit_log[4 * w + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], ...
         }
     }
 #ifdef NDT_PHASE_TIMING
