@@ -1,0 +1,739 @@
+// ndt_blob.hip -- the scene blob: validate an ndt_flat_scene, derive what the reference's plugins derive lazily in
+// prepare() (objects/ *.c), the hull boxes of the hcubes, and lay everything out as one array of 8-byte words.
+// Host code only; compiled with -ffp-contract=off like everything else (the prepare() arithmetic is part of the
+// numerical contract).
+#include "ndt_ctx.hpp"
+
+extern "C" int ndt_hip_hcube_hull_box(const ndt_flat_scene *fs, int32_t object, double *rows_out)
+{
+    if (!fs || !rows_out) return fail(NDT_E_INVALID, "null argument");
+    if (fs->abi_version != NDT_HIP_ABI_VERSION) return fail(NDT_E_INVALID, "flat scene ABI %d, library %d", fs->abi_version, NDT_HIP_ABI_VERSION);
+    if (fs->dims < 3 || fs->dims > NDT_MAX_DIMS) return fail(NDT_E_UNSUPPORTED, "dims %d", fs->dims);
+    if (object < 0 || object >= fs->n_objects || fs->objects[object].type != NDT_OBJ_HCUBE)
+        return fail(NDT_E_INVALID, "object %d is not an hcube", object);
+    const ndt_flat_object &o = fs->objects[object];
+    if (o.n_obj < 1 || o.obj_off < 0 || (int64_t)o.obj_off + o.n_obj > fs->n_obj_refs) return fail(NDT_E_INVALID, "object %d: child range", object);
+    for (int k = 0; k < o.n_obj; ++k) {
+        const int c = fs->obj_refs[o.obj_off + k];
+        if (c < 0 || c >= fs->n_objects) return fail(NDT_E_INVALID, "object %d: bad nested primitive %d", object, c);
+    }
+    std::vector<double> rows;
+    if (!hcube_hull_box(fs, o, fs->dims, rows)) return 0;
+    memcpy(rows_out, rows.data(), rows.size() * sizeof(double));
+    return 1;
+}
+
+extern "C" int ndt_hip_hcube_face_boxes(const ndt_flat_scene *fs, int32_t object, double *face_rows, uint64_t *possible)
+{
+    if (!face_rows || !possible) return fail(NDT_E_INVALID, "null argument");
+    std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
+    const int rc = ndt_hip_hcube_hull_box(fs, object, hull.data());      // validates the arguments
+    if (rc <= 0) return rc;
+    std::vector<double> rows;
+    HullFaces hf;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    memcpy(face_rows, hf.rows.data(), hf.rows.size() * sizeof(double));
+    *possible = hf.possible;
+    return hf.n_faces;
+}
+
+// ------------------------------------------------------------------ host vector math (prepare)
+//
+// Same operation order as the reference's vectNd.h (SSE2 lane-pair dot).  This file is
+// compiled with -ffp-contract=off for host and device alike.
+
+static double h_dot(const double *a, const double *b, int n)
+{
+    double s0 = a[0] * b[0];
+    double s1 = a[1] * b[1];
+    for (int i = 2; i < n; i += 2) {
+        s0 = s0 + a[i] * b[i];
+        if (i + 1 < n) s1 = s1 + a[i + 1] * b[i + 1];
+    }
+    return s0 + s1;
+}
+static void h_sub(const double *a, const double *b, double *r, int n) { for (int i = 0; i < n; ++i) r[i] = a[i] - b[i]; }
+static void h_scale(const double *a, double s, double *r, int n) { for (int i = 0; i < n; ++i) r[i] = a[i] * s; }
+static double h_len(const double *a, int n) { return sqrt(h_dot(a, a, n)); }
+static void h_unitize(double *a, int n)
+{
+    double len = h_len(a, n);
+    if (len > NDT_EPS || len < -NDT_EPS) h_scale(a, 1.0 / len, a, n);
+}
+static double h_dist(const double *a, const double *b, int n)
+{
+    double d[NDT_MAX_DIMS];
+    h_sub(a, b, d, n);
+    return h_len(d, n);
+}
+static double h_angle3(const double *p1, const double *p2, const double *p3, int n)
+{
+    // vectNd_angle3 / vectNd_angle, vectNd.c:83 / :64
+    double a[NDT_MAX_DIMS], b[NDT_MAX_DIMS];
+    h_sub(p1, p2, a, n);
+    h_sub(p3, p2, b, n);
+    double dp = h_dot(a, b, n);
+    double div = h_len(a, n) * h_len(b, n);
+    if (fabs(div) > NDT_EPS) return acos(dp / div);
+    return -1;
+}
+
+// ------------------------------------------------------------------ scene validation + blob
+
+namespace {
+
+struct BlobBuilder {
+    std::vector<double> w;
+    int words() const { return (int)w.size(); }
+    int push(double x) { w.push_back(x); return words() - 1; }
+    int push_vec(const double *v, int n) { int at = words(); for (int i = 0; i < n; ++i) w.push_back(v[i]); return at; }
+    int push_ints(int a, int b)
+    {
+        double d;
+        int pair[2] = { a, b };
+        memcpy(&d, pair, sizeof(d));
+        w.push_back(d);
+        return words() - 1;
+    }
+    // object reference list: one word per entry {int object, int header flags}; the flags are
+    // patched in once the headers exist, so a list scan needs one LDS read per entry, not two
+    int push_ref_list(const std::vector<int> &v, std::vector<int> &patch)
+    {
+        int at = words();
+        for (size_t i = 0; i < v.size(); ++i) {
+            patch.push_back(words());
+            push_ints(v[i], 0);
+        }
+        if (v.empty()) push_ints(0, 0);
+        return at;
+    }
+    void set_ints(int word, int a, int b)
+    {
+        int pair[2] = { a, b };
+        memcpy(&w[word], pair, sizeof(double));
+    }
+};
+
+bool vec_ok(const ndt_flat_scene *fs, int64_t off, int64_t count)
+{
+    return off >= 0 && count >= 0 && off + count * fs->dims <= fs->n_vecs;
+}
+
+} // namespace
+
+// Renumber the kd-tree in preorder (left child = parent + 1) and check it is a tree.
+static int kd_preorder(const ndt_flat_scene *fs, int node, int depth, std::vector<int> &order, std::vector<char> &seen,
+                       int &max_depth)
+{
+    if (node < 0 || node >= fs->n_kd_nodes) return fail(NDT_E_INVALID, "kd node index %d out of range", node);
+    if (seen[node]) return fail(NDT_E_INVALID, "kd node %d reached twice", node);
+    seen[node] = 1;
+    order.push_back(node);
+    if (depth > max_depth) max_depth = depth;
+    const ndt_flat_kdnode &k = fs->kd_nodes[node];
+    if (k.dim >= 0) {
+        if (k.dim >= fs->dims) return fail(NDT_E_INVALID, "kd node %d splits dimension %d of a %d-D scene", node, k.dim, fs->dims);
+        int rc = kd_preorder(fs, k.left, depth + 1, order, seen, max_depth);
+        if (rc) return rc;
+        rc = kd_preorder(fs, k.right, depth + 1, order, seen, max_depth);
+        if (rc) return rc;
+    } else {
+        if (k.num < 0 || k.first < 0 || (int64_t)k.first + k.num > fs->n_leaf_refs)
+            return fail(NDT_E_INVALID, "kd leaf %d item range out of bounds", node);
+        for (int i = 0; i < k.num; ++i) {
+            int id = fs->leaf_refs[k.first + i];
+            if (id < 0 || id >= fs->n_items) return fail(NDT_E_INVALID, "kd leaf %d lists object %d (n_items %d)", node, id, fs->n_items);
+        }
+    }
+    return NDT_OK;
+}
+
+// Hull box of an hcube: an oriented box that contains every point the faces' intersect() can
+// return.  NOT part of the reference's algorithm -- an exactness-preserving cull, like the
+// kd-tree itself: a ray that misses the box cannot hit any face in the reference's own
+// arithmetic, so trace() over the faces (hcube.c:241) returns "no hit", which is what the device
+// gets by not scanning them.
+//
+// What orthotope.intersect (orthotope.c:150-300) accepts, with y = X - pos, unit basis columns
+// B = [b_1..b_m] and A = B B^T:  |(A - I) y|^2 <= 2*EPSILON  (the `qc -= EPSILON` roots give
+// exactly EPSILON, the closest-approach branch |dist| <= EPSILON) and, within_orthotope
+// (orthotope.c:126-148),  -EPSILON <= y.b_i <= |dir_i| + EPSILON.  Split y = y_par + y_perp
+// (span of B and its complement): |(A-I)y|^2 = |(A-I)y_par|^2 + |y_perp|^2.  In the orthonormal
+// eigenvectors e_j = B w_j / sqrt(l_j) of A on span(B) (G = B^T B = W diag(l) W^T), with
+// alpha_j = y.e_j:   |alpha_j| <= d/|l_j - 1|   and   alpha_j = (w_j . c)/sqrt(l_j) for the slab
+// coordinates c_i = y.b_i in [-EPSILON, |dir_i|+EPSILON];  |y_perp| <= d;  d = sqrt(2*EPSILON).
+// For an orthogonal face (the usual hypercube) l_j = 1 and this is the face grown by EPSILON;
+// for the skewed bases scenes/random.c hands to hcube it is a small blob around pos.
+// The hcube's box is the bounding box, in one orthonormal frame, of the alpha-box corners of
+// all faces, grown by NDT_HULL_MARGIN = 0.02 > d = 0.01415 (y_perp, rounding).
+// rows: N x { unit axis[N], centre coordinate, half extent }.
+#define NDT_HULL_MARGIN 0.02
+#define NDT_HULL_DELTA 0.01485      /* sqrt(2e-4) * 1.05 */
+#define NDT_HULL_EPS 1.1e-4
+#define NDT_HULL_MAX_FACES 63       /* face boxes: one bit per face in a 64-bit word whose top bit stays clear (trace_kd) */
+
+// cyclic Jacobi: a (m x m, symmetric, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of w
+static void jacobi_eig(std::vector<double> &a, std::vector<double> &w, int m)
+{
+    w.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) w[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) off += a[(size_t)i * m + j] * a[(size_t)i * m + j];
+        if (off < 1e-26) break;
+        for (int pi = 0; pi < m; ++pi)
+            for (int q = pi + 1; q < m; ++q) {
+                const double apq = a[(size_t)pi * m + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (a[(size_t)q * m + q] - a[(size_t)pi * m + pi]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < m; ++k) {       // columns
+                    const double akp = a[(size_t)k * m + pi], akq = a[(size_t)k * m + q];
+                    a[(size_t)k * m + pi] = c * akp - sn * akq;
+                    a[(size_t)k * m + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < m; ++k) {       // rows
+                    const double apk = a[(size_t)pi * m + k], aqk = a[(size_t)q * m + k];
+                    a[(size_t)pi * m + k] = c * apk - sn * aqk;
+                    a[(size_t)q * m + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < m; ++k) {
+                    const double wkp = w[(size_t)k * m + pi], wkq = w[(size_t)k * m + q];
+                    w[(size_t)k * m + pi] = c * wkp - sn * wkq;
+                    w[(size_t)k * m + q] = sn * wkp + c * wkq;
+                }
+            }
+    }
+}
+
+// corner points (world coordinates) of a box that contains the in-span part of one face's acceptance region
+static bool face_region_corners(const double *pos, const double *dir, int m, int n, std::vector<double> &pts)
+{
+    if (m == 0) {
+        pts.insert(pts.end(), pos, pos + n);
+        return true;
+    }
+    std::vector<double> bu((size_t)m * n), len((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        len[i] = h_len(dir + i * n, n);
+        if (!(len[i] > 0) || !std::isfinite(len[i])) return false;
+        memcpy(&bu[(size_t)i * n], dir + i * n, n * sizeof(double));
+        h_unitize(&bu[(size_t)i * n], n);       // vectNd_unitize, as orthotope.c:37
+    }
+    std::vector<double> g((size_t)m * m), w;
+    double off = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            double d = 0;
+            for (int q = 0; q < n; ++q) d += bu[(size_t)i * n + q] * bu[(size_t)j * n + q];
+            g[(size_t)i * m + j] = d;
+            if (i != j && fabs(d) > off) off = fabs(d);
+        }
+    if (off < 1e-12) {
+        // orthogonal face: keep its own axes (an eigen-solver may return any rotation of a repeated eigenvalue)
+        w.assign((size_t)m * m, 0.0);
+        for (int i = 0; i < m; ++i) w[(size_t)i * m + i] = 1.0;
+    } else {
+        jacobi_eig(g, w, m);
+    }
+    std::vector<double> e((size_t)m * n), lo((size_t)m), hi((size_t)m);
+    for (int j = 0; j < m; ++j) {
+        const double l = g[(size_t)j * m + j];
+        if (!(l > 1e-10) || !std::isfinite(l)) return false;       // dependent directions
+        const double sl = sqrt(l);
+        double slo = 0, shi = 0;
+        for (int q = 0; q < n; ++q) e[(size_t)j * n + q] = 0;
+        for (int i = 0; i < m; ++i) {
+            const double wij = w[(size_t)i * m + j];
+            for (int q = 0; q < n; ++q) e[(size_t)j * n + q] += bu[(size_t)i * n + q] * wij / sl;
+            const double c0 = -NDT_HULL_EPS * wij, c1 = (len[i] + NDT_HULL_EPS) * wij;
+            slo += (c0 < c1 ? c0 : c1) / sl;
+            shi += (c0 < c1 ? c1 : c0) / sl;
+        }
+        lo[j] = slo;
+        hi[j] = shi;
+        if (fabs(l - 1) > 1e-9) {
+            const double r = NDT_HULL_DELTA / fabs(l - 1);
+            if (-r > lo[j]) lo[j] = -r;
+            if (r < hi[j]) hi[j] = r;
+        }
+        if (lo[j] > hi[j]) return true;     // empty region: this face can never be hit; contributes nothing
+    }
+    for (unsigned bits = 0; bits < (1u << m); ++bits) {
+        std::vector<double> pt(pos, pos + n);
+        for (int j = 0; j < m; ++j) {
+            const double aj = (bits & (1u << j)) ? hi[j] : lo[j];
+            for (int q = 0; q < n; ++q) pt[q] += aj * e[(size_t)j * n + q];
+        }
+        pts.insert(pts.end(), pt.begin(), pt.end());
+    }
+    return true;
+}
+
+bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces)
+{
+    std::vector<double> pts;
+    std::vector<size_t> face_begin;             // first corner point of every face (its region's corners are consecutive)
+    std::vector<std::vector<double>> axes;      // unit face axes, for the aligned candidate frame
+    for (int k = 0; k < o.n_obj; ++k) {
+        face_begin.push_back(pts.size() / n);
+        const ndt_flat_object &f = fs->objects[fs->obj_refs[o.obj_off + k]];
+        if (f.type != NDT_OBJ_ORTHOTOPE || f.n_flag < 1 || f.n_pos < 1) return false;
+        if (f.flag_off < 0 || (int64_t)f.flag_off + f.n_flag > fs->n_flags) return false;
+        const int m = fs->flags[f.flag_off];
+        if (m < 0 || m > f.n_dir || m > n || m > 16) return false;
+        if (!vec_ok(fs, f.pos_off, 1) || !vec_ok(fs, f.dir_off, m)) return false;
+        if (!face_region_corners(fs->vecs + f.pos_off, fs->vecs + f.dir_off, m, n, pts)) return false;
+        for (int a = 0; a < m; ++a) {
+            std::vector<double> u(fs->vecs + f.dir_off + a * n, fs->vecs + f.dir_off + (a + 1) * n);
+            h_unitize(u.data(), n);
+            axes.push_back(u);
+        }
+    }
+    const size_t n_pts = pts.size() / n;
+    if (n_pts == 0) return false;
+    for (double x : pts)
+        if (!std::isfinite(x)) return false;
+
+    // candidate orthonormal frames: Gram-Schmidt of the face axes, principal axes of the points, world axes
+    auto complete = [&](std::vector<std::vector<double>> &frame, const std::vector<std::vector<double>> &cands, double keep) {
+        for (const auto &a : cands) {
+            if ((int)frame.size() >= n) break;
+            std::vector<double> r(a);
+            for (const auto &u : frame) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += a[c] * u[c];
+                for (int c = 0; c < n; ++c) r[c] -= d * u[c];
+            }
+            const double l = h_len(r.data(), n);
+            if (l > keep) {
+                for (int c = 0; c < n; ++c) r[c] /= l;
+                frame.push_back(r);
+            }
+        }
+    };
+    std::vector<std::vector<double>> world;
+    for (int j = 0; j < n; ++j) {
+        std::vector<double> e((size_t)n, 0.0);
+        e[j] = 1.0;
+        world.push_back(e);
+    }
+    std::vector<std::vector<std::vector<double>>> frames(3);
+    complete(frames[0], axes, 0.5);
+    {
+        std::vector<double> mean((size_t)n, 0.0), cov((size_t)n * n, 0.0), w;
+        for (size_t i = 0; i < n_pts; ++i)
+            for (int c = 0; c < n; ++c) mean[c] += pts[i * n + c] / (double)n_pts;
+        for (size_t i = 0; i < n_pts; ++i)
+            for (int a = 0; a < n; ++a)
+                for (int c = 0; c < n; ++c) cov[(size_t)a * n + c] += (pts[i * n + a] - mean[a]) * (pts[i * n + c] - mean[c]);
+        jacobi_eig(cov, w, n);
+        std::vector<std::vector<double>> pc;
+        for (int j = 0; j < n; ++j) {
+            std::vector<double> u((size_t)n);
+            for (int c = 0; c < n; ++c) u[c] = w[(size_t)c * n + j];
+            pc.push_back(u);
+        }
+        complete(frames[1], pc, 0.5);
+    }
+    double best_cost = 0;
+    int best = -1;
+    std::vector<double> best_rows;
+    for (int fi = 0; fi < 3; ++fi) {
+        auto &frame = frames[fi];
+        for (double keep = 0.5; (int)frame.size() < n && keep > 1e-4; keep *= 0.5) complete(frame, world, keep);
+        if ((int)frame.size() < n) continue;
+        std::vector<double> cand, half((size_t)n);
+        for (int a = 0; a < n; ++a) {
+            double lo = 1e300, hi = -1e300;
+            for (size_t i = 0; i < n_pts; ++i) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += pts[i * n + c] * frame[a][c];
+                if (d < lo) lo = d;
+                if (d > hi) hi = d;
+            }
+            cand.insert(cand.end(), frame[a].begin(), frame[a].end());
+            cand.push_back(0.5 * (lo + hi));
+            half[a] = 0.5 * (hi - lo) + NDT_HULL_MARGIN;
+            cand.push_back(half[a]);
+        }
+        // what a random ray sees of a box grows with its surface: sum over axes of the product of the other extents
+        double cost = 0;
+        for (int a = 0; a < n; ++a) {
+            double prod = 1;
+            for (int c = 0; c < n; ++c)
+                if (c != a) prod *= half[c];
+            cost += prod;
+        }
+        if (best < 0 || cost < best_cost) {
+            best = fi;
+            best_cost = cost;
+            best_rows = cand;
+        }
+    }
+    if (best < 0) return false;
+    rows = best_rows;
+    if (faces) {
+        // Every face's own box in the chosen frame.  The hull box is the union of these: a ray that misses box f
+        // cannot produce a point face f's intersect() accepts (same argument, one face at a time), so the device
+        // scans only the faces whose box the ray meets -- of the 2-D faces of a 4-D hcube, usually none or two.
+        faces->rows.clear();
+        faces->possible = 0;
+        faces->n_faces = 0;
+        if (o.n_obj <= NDT_HULL_MAX_FACES) {
+            faces->n_faces = o.n_obj;
+            face_begin.push_back(n_pts);
+            for (int k = 0; k < o.n_obj; ++k) {
+                const size_t p0 = face_begin[k], p1 = face_begin[k + 1];
+                if (p1 > p0) faces->possible |= 1ull << k;
+                for (int a = 0; a < n; ++a) {
+                    double lo = 1e300, hi = -1e300;
+                    for (size_t i = p0; i < p1; ++i) {
+                        double d = 0;
+                        for (int c = 0; c < n; ++c) d += pts[i * n + c] * rows[(size_t)a * (n + 2) + c];
+                        if (d < lo) lo = d;
+                        if (d > hi) hi = d;
+                    }
+                    if (p1 == p0) lo = hi = 0;
+                    faces->rows.push_back(0.5 * (lo + hi));
+                    faces->rows.push_back(0.5 * (hi - lo) + NDT_HULL_MARGIN);
+                }
+            }
+        }
+    }
+    return true;
+}
+
+int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
+{
+    const int n = fs->dims;
+    BlobBuilder b;
+    SceneDesc sd{};
+    sd.n_items = fs->n_items;
+    sd.n_objects = fs->n_objects;
+    sd.n_kd_nodes = fs->n_kd_nodes;
+    sd.n_inf = fs->n_inf;
+    sd.n_lights = fs->n_lights;
+    sd.mask_words = (fs->n_items + 63) / 64;
+    if (sd.mask_words < 1) sd.mask_words = 1;
+
+    // ---- kd nodes, preorder
+    std::vector<int> order;
+    std::vector<char> seen((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), 0);
+    int max_depth = 0;
+    if (fs->n_kd_nodes > 0) {
+        int rc = kd_preorder(fs, 0, 1, order, seen, max_depth);
+        if (rc) return rc;
+        if (max_depth > NDT_KD_STACK)
+            return fail(NDT_E_UNSUPPORTED, "kd-tree depth %d exceeds the traversal stack (%d)", max_depth, NDT_KD_STACK);
+    }
+    sd.kd_depth = max_depth;
+    std::vector<int> new_index((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), -1);
+    for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+    sd.n_kd_nodes = (int)order.size();
+    std::vector<int> leaf_list;
+    sd.off_kd = b.words();
+    for (size_t i = 0; i < order.size(); ++i) {
+        const ndt_flat_kdnode &k = fs->kd_nodes[order[i]];
+        if (k.dim >= 0) {
+            if (new_index[k.left] != (int)i + 1) return fail(NDT_E_INVALID, "internal: preorder numbering");
+            b.push_ints(k.dim, new_index[k.right]);
+            b.push(k.boundary);
+        } else {
+            b.push_ints(-1, 0);
+            b.push_ints((int)leaf_list.size(), k.num);
+            for (int j = 0; j < k.num; ++j) leaf_list.push_back(fs->leaf_refs[k.first + j]);
+        }
+    }
+    std::vector<int> ref_patch;
+    sd.off_leaf = b.push_ref_list(leaf_list, ref_patch);
+    std::vector<int> inf_list;
+    for (int i = 0; i < fs->n_inf; ++i) {
+        int id = fs->inf_refs[i];
+        if (id < 0 || id >= fs->n_items) return fail(NDT_E_INVALID, "infinite list names object %d (n_items %d)", id, fs->n_items);
+        inf_list.push_back(id);
+    }
+    sd.off_inf = b.push_ref_list(inf_list, ref_patch);
+
+    // ---- object headers (filled after params are placed), bounding spheres, root box
+    sd.off_hdr = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        b.push_ints(0, 0);
+        b.push_ints(0, 0);
+    }
+    sd.off_bs = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        if (!vec_ok(fs, o.bounds_center_off, 1)) return fail(NDT_E_INVALID, "object %d: bounds centre out of range", i);
+        b.push_vec(fs->vecs + o.bounds_center_off, n);
+        b.push(o.bounds_radius);
+        b.push(o.bounds_radius * o.bounds_radius);      // bounding.c:22
+    }
+    if (!vec_ok(fs, fs->bb_lower_off, 1) || !vec_ok(fs, fs->bb_upper_off, 1)) return fail(NDT_E_INVALID, "root box out of range");
+    sd.off_bb = b.push_vec(fs->vecs + fs->bb_lower_off, n);
+    b.push_vec(fs->vecs + fs->bb_upper_off, n);
+
+    // ---- nested primitive lists
+    std::vector<int> child_list;
+    std::vector<int> child_first((size_t)(fs->n_objects > 0 ? fs->n_objects : 1), 0);
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        child_first[i] = (int)child_list.size();
+        if (o.type == NDT_OBJ_HCUBE) {
+            if (o.n_obj < 1) return fail(NDT_E_UNSUPPORTED, "object %d: hcube without faces (supply add_faces output)", i);
+            if (o.obj_off < 0 || (int64_t)o.obj_off + o.n_obj > fs->n_obj_refs) return fail(NDT_E_INVALID, "object %d: child range", i);
+            for (int k = 0; k < o.n_obj; ++k) {
+                int c = fs->obj_refs[o.obj_off + k];
+                if (c < 0 || c >= fs->n_objects || fs->objects[c].type == NDT_OBJ_HCUBE)
+                    return fail(NDT_E_INVALID, "object %d: bad nested primitive %d", i, c);
+                child_list.push_back(c);
+            }
+        }
+    }
+    sd.off_child = b.push_ref_list(child_list, ref_patch);
+
+    // ---- per-type parameters = the plugins' prepare() output
+    sd.off_params = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        if (o.type < 0 || o.type >= NDT_OBJ_TYPE_COUNT) return fail(NDT_E_UNSUPPORTED, "object %d: unknown type %d", i, o.type);
+        if (!vec_ok(fs, o.pos_off, o.n_pos) || !vec_ok(fs, o.dir_off, o.n_dir)) return fail(NDT_E_INVALID, "object %d: vector range", i);
+        if (o.n_size < 0 || o.size_off < 0 || (int64_t)o.size_off + o.n_size > fs->n_sizes) return fail(NDT_E_INVALID, "object %d: size range", i);
+        if (o.n_flag < 0 || o.flag_off < 0 || (int64_t)o.flag_off + o.n_flag > fs->n_flags) return fail(NDT_E_INVALID, "object %d: flag range", i);
+        const double *pos = fs->vecs + o.pos_off;
+        const double *dir = fs->vecs + o.dir_off;
+        const double *size = fs->sizes + o.size_off;
+        const int *flag = fs->flags + o.flag_off;
+        int flags = o.type;
+        if (o.bounds_radius > 0) flags |= NDT_F_GATE;
+        if (o.transparent) flags |= NDT_F_TRANSPARENT;
+        int aux0 = 0, aux1 = 0;
+        const int p = b.words() - sd.off_params;
+        double tmp[NDT_MAX_DIMS], ax[NDT_MAX_DIMS];
+        auto need = [&](bool ok, const char *what) -> int {
+            return ok ? NDT_OK : fail(NDT_E_INVALID, "object %d: %s", i, what);
+        };
+        int rc = NDT_OK;
+        switch (o.type) {
+        case NDT_OBJ_SPHERE:        // sphere.c:18-32 (pow(r,2.0) == r*r)
+            if ((rc = need(o.n_pos >= 1 && o.n_size >= 1, "sphere needs 1 pos, 1 size"))) return rc;
+            b.push_vec(pos, n);
+            b.push(size[0] * size[0]);
+            break;
+        case NDT_OBJ_HPLANE:
+        case NDT_OBJ_HDISK:
+            if ((rc = need(o.n_pos >= 1 && o.n_dir >= 1 && (o.type == NDT_OBJ_HPLANE || o.n_size >= 1), "hplane/hdisk parameters"))) return rc;
+            b.push_vec(pos, n);
+            b.push_vec(dir, n);
+            b.push(o.type == NDT_OBJ_HDISK ? size[0] : 0.0);
+            break;
+        case NDT_OBJ_CYLINDER: {    // cylinder.c:22-40
+            if ((rc = need(o.n_pos >= 2 && o.n_size >= 1, "cylinder needs 2 pos, 1 size"))) return rc;
+            h_sub(pos + n, pos, ax, n);
+            h_unitize(ax, n);
+            b.push_vec(pos, n);
+            b.push_vec(ax, n);
+            b.push(h_dist(pos + n, pos, n));
+            b.push(h_dot(ax, ax, n));
+            b.push(h_dot(pos, ax, n));
+            b.push(size[0]);
+            if (o.n_flag > 1 && flag[1] != 0) flags |= NDT_F_INF_ENDS;     // cylinder.c:87
+            break;
+        }
+        case NDT_OBJ_HCYLINDER: {   // hcylinder.c:23-54
+            const int m = n - 2;
+            if ((rc = need(o.n_pos >= n - 1 && o.n_size >= 1, "hcylinder needs dims-1 pos, 1 size"))) return rc;
+            b.push_vec(pos, n);
+            b.push(size[0]);
+            for (int k = 0; k < m; ++k) {
+                h_sub(pos + (k + 1) * n, pos, ax, n);
+                h_unitize(ax, n);
+                b.push_vec(ax, n);
+                b.push(h_dist(pos + (k + 1) * n, pos, n));
+                b.push(h_dot(ax, ax, n));
+                b.push(h_dot(pos, ax, n));
+            }
+            aux1 = m;
+            if (o.n_flag != 0 && flag[0] != 0) flags |= NDT_F_INF_ENDS;    // hcylinder.c:107
+            break;
+        }
+        case NDT_OBJ_ORTHOTOPE: {   // orthotope.c:23-54
+            if ((rc = need(o.n_flag >= 1 && o.n_pos >= 1, "orthotope needs 1 pos, 1 flag"))) return rc;
+            const int m = flag[0];
+            if ((rc = need(m >= 0 && m <= o.n_dir && m <= n, "orthotope flag[0] vs directions"))) return rc;
+            b.push_vec(pos, n);
+            b.push(0.0);
+            for (int k = 0; k < m; ++k) {
+                memcpy(ax, dir + k * n, n * sizeof(double));
+                h_unitize(ax, n);
+                b.push_vec(ax, n);
+                b.push(h_len(dir + k * n, n));
+                b.push(h_dot(ax, ax, n));       // BdB
+                b.push(h_dot(pos, ax, n));      // BdP
+            }
+            aux1 = m;
+            break;
+        }
+        case NDT_OBJ_HCUBE: {
+            aux0 = child_first[i];
+            aux1 = o.n_obj;
+            std::vector<double> rows;
+            HullFaces hf;
+            if (!getenv("NDT_HIP_NO_HULL_BOX") && hcube_hull_box(fs, o, n, rows, &hf)) {
+                flags |= NDT_F_BOX;
+                for (double x : rows) b.push(x);
+                if (hf.n_faces > 0 && !getenv("NDT_HIP_NO_FACE_BOX")) {
+                    // { possible-faces mask } + per face N x { centre, half extent }
+                    flags |= NDT_F_FACEBOX;
+                    b.push_ints((int)(hf.possible & 0xffffffffull), (int)(hf.possible >> 32));
+                    for (double x : hf.rows) b.push(x);
+                }
+            } else {
+                b.push(0.0);
+            }
+            break;
+        }
+        case NDT_OBJ_HFACET: {      // hfacet.c:43-87 + the ray-invariant dots of get_barycentric (hfacet.c:176-181)
+            if ((rc = need(o.n_pos >= 3 && o.n_flag >= 1, "hfacet needs 3 pos, 1 flag"))) return rc;
+            if ((rc = need(!flag[0] || o.n_dir >= 3, "hfacet with vertex normals needs 3 dir"))) return rc;
+            double edge[3][NDT_MAX_DIMS], uedge0[NDT_MAX_DIMS], perp[NDT_MAX_DIMS];
+            for (int k = 0; k < 3; ++k) h_sub(pos + ((k + 1) % 3) * n, pos + k * n, edge[k], n);
+            memcpy(uedge0, edge[0], n * sizeof(double));
+            h_unitize(uedge0, n);
+            h_scale(edge[2], -1.0, edge[2], n);
+            // vectNd_proj(edge2, edge0), vectNd.h:355
+            double bb = h_dot(edge[0], edge[0], n);
+            double ab = h_dot(edge[2], edge[0], n);
+            h_scale(edge[0], ab / bb, tmp, n);
+            h_sub(edge[2], tmp, perp, n);
+            h_unitize(perp, n);
+            b.push_vec(pos, n);
+            b.push_vec(uedge0, n);
+            b.push_vec(perp, n);
+            b.push(h_dot(uedge0, edge[0], n));  // x2
+            b.push(h_dot(perp, edge[0], n));    // y2
+            b.push(h_dot(uedge0, edge[2], n));  // x3
+            b.push(h_dot(perp, edge[2], n));    // y3
+            for (int k = 0; k < 3; ++k) {
+                if (flag[0]) b.push_vec(dir + k * n, n);
+                else { double z[NDT_MAX_DIMS] = { 0 }; b.push_vec(z, n); }
+            }
+            if (flag[0]) flags |= NDT_F_USE_NORMALS;
+            break;
+        }
+        case NDT_OBJ_FACET: {       // facet.c:42-83
+            if ((rc = need(o.n_pos >= 3 && o.n_dir >= 1, "facet needs 3 pos, 1 dir"))) return rc;
+            double edge0[NDT_MAX_DIMS], edge1[NDT_MAX_DIMS], b0[NDT_MAX_DIMS], b1[NDT_MAX_DIMS], angle[3];
+            for (int k = 0; k < 3; ++k)
+                angle[k] = h_angle3(pos + ((k + 2) % 3) * n, pos + k * n, pos + ((k + 1) % 3) * n, n);
+            h_sub(pos + n, pos, edge0, n);
+            h_sub(pos + 2 * n, pos + n, edge1, n);
+            // vectNd_orthogonalize(edge0, edge1, basis0, basis1), vectNd.c:35
+            double bb = h_dot(edge1, edge1, n);
+            double ab = h_dot(edge0, edge1, n);
+            h_scale(edge1, ab / bb, tmp, n);
+            h_sub(edge0, tmp, b0, n);
+            memcpy(b1, edge1, n * sizeof(double));
+            h_unitize(b0, n);
+            h_unitize(b1, n);
+            b.push_vec(pos, n);
+            b.push_vec(pos + n, n);
+            b.push_vec(pos + 2 * n, n);
+            b.push_vec(b0, n);
+            b.push_vec(b1, n);
+            b.push(h_dot(b0, b0, n));               // AdA, facet.c:191
+            b.push(h_dot(b1, b1, n));
+            b.push(h_dot(pos + n, b0, n));          // BdA, facet.c:200
+            b.push(h_dot(pos + n, b1, n));
+            b.push(angle[0]);
+            b.push(angle[1]);
+            b.push(angle[2]);
+            b.push_vec(dir, n);
+            break;
+        }
+        }
+        b.set_ints(sd.off_hdr + 2 * i, flags, p);
+        b.set_ints(sd.off_hdr + 2 * i + 1, aux0, aux1);
+    }
+    for (int w : ref_patch) {
+        int pair[2];
+        memcpy(pair, &b.w[w], sizeof(pair));
+        int hdr[2];
+        memcpy(hdr, &b.w[sd.off_hdr + 2 * pair[0]], sizeof(hdr));
+        b.set_ints(w, pair[0], hdr[0]);
+    }
+    sd.trace_words = b.words();
+
+    // ---- shading data: materials, lights, camera
+    sd.off_mat = b.words();
+    for (int i = 0; i < fs->n_objects; ++i) {
+        const ndt_flat_object &o = fs->objects[i];
+        b.push(o.red); b.push(o.green); b.push(o.blue);
+        b.push(o.red_r); b.push(o.green_r); b.push(o.blue_r);
+        b.push(o.refract_index);
+        b.push(o.transparent ? 1.0 : 0.0);
+    }
+    sd.off_lights = b.words();
+    int n_shadow_lights = 0;
+    bool has_area_lights = false;
+    for (int i = 0; i < fs->n_lights; ++i) {
+        const ndt_flat_light &l = fs->lights[i];
+        double zero[NDT_MAX_DIMS] = { 0 };
+        if (l.type < 0 || l.type > NDT_LIGHT_RECT) return fail(NDT_E_INVALID, "light %d: type %d", i, l.type);
+        const bool area = l.type == NDT_LIGHT_DISK || l.type == NDT_LIGHT_RECT;
+        if (area && !vec_ok(fs, l.area_off, 2)) return fail(NDT_E_INVALID, "light %d: area lights need u1 / v1 (scene.c:182-195) in the flat scene", i);
+        if (area) has_area_lights = true;
+        const bool want_pos = l.type == NDT_LIGHT_POINT || l.type == NDT_LIGHT_SPOT || area;
+        const bool want_dir = l.type == NDT_LIGHT_DIRECTIONAL || l.type == NDT_LIGHT_SPOT;
+        if (want_pos && !vec_ok(fs, l.pos_off, 1)) return fail(NDT_E_INVALID, "light %d: position missing", i);
+        if (want_dir && !vec_ok(fs, l.dir_off, 1)) return fail(NDT_E_INVALID, "light %d: direction missing", i);
+        if (l.type != NDT_LIGHT_AMBIENT) ++n_shadow_lights;
+        b.push_ints(l.type, 0);
+        b.push(l.red); b.push(l.green); b.push(l.blue);
+        b.push(l.angle);
+        b.push_vec(want_pos ? fs->vecs + l.pos_off : zero, n);
+        b.push_vec(want_dir ? fs->vecs + l.dir_off : zero, n);
+        b.push(area ? l.radius : 0.0);
+        b.push_vec(area ? fs->vecs + l.area_off : zero, n);         // u1
+        b.push_vec(area ? fs->vecs + l.area_off + n : zero, n);     // v1
+    }
+    ctx->has_area_lights = has_area_lights;
+    if (!vec_ok(fs, fs->cam_pos_off, 1) || !vec_ok(fs, fs->cam_img_orig_off, 1) || !vec_ok(fs, fs->cam_dir_x_off, 1) ||
+        !vec_ok(fs, fs->cam_dir_y_off, 1))
+        return fail(NDT_E_INVALID, "camera vectors out of range");
+    sd.off_cam = b.push_vec(fs->vecs + fs->cam_pos_off, n);
+    b.push_vec(fs->vecs + fs->cam_img_orig_off, n);
+    b.push_vec(fs->vecs + fs->cam_dir_x_off, n);
+    b.push_vec(fs->vecs + fs->cam_dir_y_off, n);
+    b.push(fs->cam_focal_distance);
+    for (int i = 0; i < 3; ++i) b.push(fs->ambient[i]);
+    for (int i = 0; i < 4; ++i) b.push(fs->background[i]);
+    // the rest of the camera, at off_cam + 4N + 8: type, hFov, vFov, leftEye, rightEye, localX, localY, localZ
+    // (camera.h:34-75; zeros where the scene does not carry them -- ndt_hip_render checks before use)
+    {
+        const int32_t offs[5] = { fs->cam_left_eye_off, fs->cam_right_eye_off, fs->cam_local_x_off, fs->cam_local_y_off,
+                                  fs->cam_local_z_off };
+        b.push((double)fs->cam_type);
+        b.push(fs->cam_h_fov);
+        b.push(fs->cam_v_fov);
+        for (int k = 0; k < 5; ++k) {
+            if (offs[k] >= 0 && !vec_ok(fs, offs[k], 1)) return fail(NDT_E_INVALID, "camera vectors out of range");
+            if (offs[k] >= 0) b.push_vec(fs->vecs + offs[k], n);
+            else for (int c = 0; c < n; ++c) b.push(0.0);
+        }
+        ctx->cam_type = fs->cam_type;
+        ctx->have_eyes = offs[0] >= 0 && offs[1] >= 0;
+        ctx->have_local_axes = offs[2] >= 0 && offs[3] >= 0 && offs[4] >= 0;
+    }
+    sd.total_words = b.words();
+
+    ctx->sd = sd;
+    ctx->blob.swap(b.w);
+    ctx->n_shadow_lights = n_shadow_lights;
+    // tier 0: trace sections fit the LDS budget and the visit mask fits registers
+    const bool fits_lds = (size_t)sd.trace_words * sizeof(double) <= NDT_TRACE_LDS_LIMIT;
+    ctx->tier = (fits_lds && sd.mask_words <= NDT_MASK_REG_WORDS) ? 0 : 1;
+    return NDT_OK;
+}

@@ -1,0 +1,145 @@
+// ndt_ctx.hpp -- what the host-side translation units of libndt_hip.so share: the context, the error
+// convention, and the internal entry points between them.
+//
+//   ndt_api.hip      create / destroy / upload / trace_rays / quantize: the plain C ABI of include/ndt_hip.h
+//   ndt_blob.hip     scene validation, the plugins' prepare() data, hull boxes: the scene blob (host code only)
+//   ndt_frame.hip    workspace + one pass of the ray pipeline over a set of primaries (render_pass)
+//   ndt_aa.hip       Whitted's recursive anti-aliasing on top of render_pass
+//   ndt_sampled.hip  -n samples > 1, lens, area lights on top of render_pass
+//   ndt_render.hip   ndt_hip_render*: argument checks and the choice between the three
+//   ndt_multi.hip    one frame over several contexts / devices
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ndt_hip.h"
+#include "ndt_kernels.hpp"
+
+namespace ndt_impl {
+
+// sets the calling thread's ndt_hip_last_error() text and returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+} // namespace ndt_impl
+using namespace ndt_impl;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(NDT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+struct ndt_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    const NdtKernelTable *kt = nullptr;
+    int dims = 0;
+    bool have_scene = false;
+    double aperture_radius = 0.0;   // camera.h:46 of the uploaded scene
+    int cam_type = 0;
+    bool have_eyes = false, have_local_axes = false;
+    bool has_area_lights = false;   // LIGHT_DISK / LIGHT_RECT: every render is stochastic (ndt.c:116-147)
+    SceneDesc sd{};
+    std::vector<double> blob;
+    double *d_blob = nullptr;
+    size_t d_blob_words = 0;
+    int tier = 0;
+    int n_shadow_lights = 0;
+    // workspace
+    Workspace ws{};
+    std::vector<void *> ws_allocs;
+    std::vector<std::pair<void *, size_t>> pool;    // scratch of the multi-pass renderers (AaBuffers)
+    long long ws_dims = 0;
+    long long ws_slab_words = 0;
+    int ws_nseg = 0;
+    void *d_out = nullptr;          // staging for ndt_hip_render (host output)
+    size_t d_out_bytes = 0;
+    int *h_counters = nullptr;      // pinned
+    LevelRange *h_levels = nullptr; // pinned, NDT_MAX_LEVELS + 1
+    LevelRange *h_mail = nullptr;   // mapped + coherent: bounce ranges posted by k_level_step while the frame runs
+    unsigned long long *h_mail_tag = nullptr;
+    LevelRange *d_mail = nullptr;   // the device's view of the two
+    unsigned long long *d_mail_tag = nullptr;
+    unsigned long long frame_tag = 0;
+    unsigned long long *h_done = nullptr;   // mapped + coherent: the frame's closing record (k_frame_done), [7] = its tag
+    unsigned long long *d_done = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace ndt_impl {
+
+// ndt_blob.hip
+struct HullFaces {
+    // per face of the hcube, in the hull box's frame: N x { centre coordinate, half extent } -- the face's own
+    // box, same derivation and margin as the hull box; possible bit f clear = face f can never be hit
+    std::vector<double> rows;
+    unsigned long long possible = 0;
+    int n_faces = 0;
+};
+bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);
+int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs);
+
+// ndt_frame.hip
+void free_workspace(ndt_hip_ctx *ctx);
+int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap);
+int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth = nullptr);
+void launch_fill_black(hipStream_t s, double *rgba, long long n_pixels);
+void add_stats(ndt_render_stats &acc, const ndt_render_stats &st);
+
+// ndt_aa.hip / ndt_sampled.hip
+int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);
+int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);
+
+// One slot of a device-side list for every lane that wants one, with ONE atomic per wavefront (a counter serves ~150
+// returning atomics per us: a list appended to by every thread of a 2-million-thread launch queues for milliseconds).
+// Every lane of the wavefront has to call it.
+__device__ __forceinline__ int wave_append(int *counter, bool want)
+{
+    const unsigned long long vote = __ballot(want);
+    if (vote == 0ull) return 0;
+    const int lane = __lane_id(), leader = __ffsll((long long)vote) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(vote));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(vote & ((1ull << lane) - 1ull));
+}
+
+// Scratch buffers of the multi-pass renderers (anti-aliasing levels, sample rounds, anaglyph eyes).  The
+// requests of a frame come in the same order every frame, so the k-th request reuses the k-th
+// allocation of the context's pool (grown when too small) instead of a hipMalloc / hipFree pair, each of
+// which synchronises the device.
+struct AaBuffers {
+    ndt_hip_ctx *ctx;
+    size_t next = 0;
+    explicit AaBuffers(ndt_hip_ctx *c) : ctx(c) {}
+    template <typename T> int get(T **ptr, size_t count)
+    {
+        const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
+        if (next == ctx->pool.size()) ctx->pool.push_back({ nullptr, 0 });
+        auto &slot = ctx->pool[next++];
+        if (slot.second < bytes) {
+            if (slot.first) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(slot.first);
+                slot = { nullptr, 0 };
+            }
+            const size_t want = bytes + bytes / 4;          // some head room: frame-to-frame counts vary
+            void *q = nullptr;
+            hipError_t e = hipMalloc(&q, want);
+            if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", want, hipGetErrorString(e));
+            slot = { q, want };
+        }
+        *ptr = (T *)slot.first;
+        return NDT_OK;
+    }
+};
+
+} // namespace ndt_impl

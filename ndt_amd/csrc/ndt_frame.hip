@@ -1,0 +1,677 @@
+// ndt_frame.hip -- the device workspace and ONE pass of the ray pipeline over a set of primaries: primary rays, the
+// bounce loop, bottom-up resolve, per-primary colour.  render_image (ndt.c:900) for the deterministic path is one
+// such pass; recursive anti-aliasing and the sampled paths call it once per level / round.
+#include "ndt_ctx.hpp"
+
+void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
+{
+    for (void *p : ctx->ws_allocs) (void)hipFree(p);
+    ctx->ws_allocs.clear();
+    memset(&ctx->ws, 0, sizeof(ctx->ws));
+    ctx->ws_slab_words = 0;
+    ctx->ws_dims = 0;
+    ctx->ws_nseg = 0;
+}
+
+// ------------------------------------------------------------------ workspace
+
+template <typename T> static int ws_alloc(ndt_hip_ctx *ctx, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
+    ctx->ws_allocs.push_back(q);
+    *p = (T *)q;
+    return NDT_OK;
+}
+
+int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
+{
+    Workspace &ws = ctx->ws;
+    const bool need_slab = ctx->tier == 1;
+    const long long slab_lanes = 2048LL * NDT_TRACE_BLOCK;
+    const long long slab_words = need_slab ? slab_lanes * ctx->sd.mask_words : 0;
+    if (ws.cap >= cap && ws.sh_cap >= sh_cap && ctx->ws_dims == ctx->dims && ctx->ws_slab_words >= slab_words &&
+        ctx->ws_nseg >= ctx->n_shadow_lights)
+        return NDT_OK;
+    if (cap < ws.cap) cap = ws.cap;
+    if (sh_cap < ws.sh_cap) sh_cap = ws.sh_cap;
+    cap = (cap + 63) & ~63LL;           // vectors are stored in tiles of 64 slots (load_soa / store_soa)
+    sh_cap = (sh_cap + 63) & ~63LL;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_workspace(ctx);
+    const int n = ctx->dims;
+    int rc;
+    ws.cap = cap;
+    ws.sh_cap = sh_cap;
+    if ((rc = ws_alloc(ctx, &ws.ray_o, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.depth, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.rng_key, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_p, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.hit_n, (size_t)n * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.clr, (size_t)3 * cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.child_refl, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.child_refr, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sh_idx, (size_t)cap * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1)))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sh_mask, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.count, (size_t)cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.so, (size_t)n * sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sv, (size_t)n * sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.slim, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return rc;
+    if (getenv("NDT_HIP_SHADE_PROBE") && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
+    ws.mask_slab_lanes = slab_lanes;
+    if (need_slab) {
+        if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return rc;
+    }
+    ctx->ws_slab_words = slab_words;
+    ctx->ws_dims = ctx->dims;
+    ctx->ws_nseg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ dimension-independent kernels
+
+// Everything a frame needs reset, in one launch (five small copies / fills of 10 us each before): node tail and
+// overflow flags, the work-queue heads of the launches the frame can have, both parities of the shadow-segment
+// counters, the reference-ray partial sums, the diagnostic words, and the primaries' range.
+__global__ void k_frame_init(Workspace ws, int n_primary, LevelRange level0, int queue_ints)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int k = i; k < queue_ints; k += stride) ws.counters[NDT_CNT_QUEUE + k] = 0;
+    for (int k = i; k < NDT_CNT_TOTAL - NDT_CNT_SEG; k += stride) ws.counters[NDT_CNT_SEG + k] = 0;
+    for (int k = i; k < 64 * 8; k += stride) ws.ref_rays[k] = 0ull;
+    for (int k = i; k < 160; k += stride) ws.dbg[k] = 0ull;
+    if (i < 4) ws.counters[i] = (i == 0) ? n_primary : 0;
+    if (i == 0) ws.levels[0] = level0;
+}
+
+// The frame's closing record, written to host-visible memory by the last kernel of the frame: the host polls its
+// tag instead of queueing three small read-backs and synchronising the stream.  One wavefront.
+//   [0] node tail  [1] overflow flags  [2] shadow slots wanted  [3] shadow rays of the frame  [4] bounces with nodes
+//   [5] rays the reference would have traced  [7] tag
+__global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, unsigned long long tag)
+{
+    const int lane = threadIdx.x;
+    unsigned long long ref = ws.ref_rays[8 * lane];         // 64 partial sums, one 64-byte line each
+    for (int d = 32; d > 0; d >>= 1) ref += __shfl_xor(ref, d, 64);
+    if (lane != 0) return;
+    long long shadow = 0;
+    int used = 0;
+    for (int b = 0; b < n_run; ++b) {
+        if (ws.levels[b].count <= 0) break;
+        shadow += ws.levels[b].n_shadow;
+        ++used;
+    }
+    done[0] = (unsigned long long)(long long)ws.counters[0];
+    done[1] = (unsigned long long)(long long)ws.counters[2];
+    done[2] = (unsigned long long)(long long)ws.counters[3];
+    done[3] = (unsigned long long)shadow;
+    done[4] = (unsigned long long)used;
+    done[5] = ref;
+    __threadfence_system();
+    __hip_atomic_store(&done[7], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// After shade_emit(level) has spawned the next bounce: publish its range, note the shadow rays
+// this bounce emitted, and clear the other parity's segment counters for the next shade_emit.
+// The range is also posted to host-visible memory: k_level_step runs early in a bounce (before
+// its long trace launch), so by the time the host wants to enqueue the next bounce the answer
+// is there and the GPU never waits for the host.  One wavefront.
+__global__ void k_level_step(Workspace ws, int level, int n_seg, unsigned long long tag)
+{
+    const int lane = threadIdx.x;
+    int *seg = NDT_SEG_COUNTERS(ws, level);
+    long long mine = (lane < n_seg) ? seg[lane] : 0;
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    NDT_SEG_COUNTERS(ws, level + 1)[lane] = 0;
+    if (lane != 0) return;
+    const LevelRange cur = ws.levels[level];
+    ws.levels[level].n_shadow = mine;
+    LevelRange next;
+    next.begin = cur.begin + cur.count;
+    next.count = (long long)ws.counters[0] - next.begin;
+    next.n_shadow = 0;
+    if (next.count < 0 || ws.counters[2] != 0) next.count = 0;         // node pool overflow: the host retries
+    next.seg_stride = (next.count + 63) & ~63LL;
+    if ((long long)n_seg * next.seg_stride > ws.sh_cap) {
+        // the shadow queue cannot hold this bounce: flag it, tell the host how much it needs, stop here
+        atomicOr(&ws.counters[2], 2);
+        const long long need = (long long)n_seg * next.seg_stride;
+        ws.counters[3] = need > 0x7fffffffLL ? 0x7fffffff : (int)need;
+        next.count = 0;
+        next.seg_stride = 0;
+    }
+    ws.levels[level + 1] = next;
+    // ... and for the host, which enqueues bounce level+1 only once it knows there is one
+    ws.mail[level + 1] = next;
+    __threadfence_system();
+    __hip_atomic_store(&ws.mail_tag[level + 1], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Bottom-up combine of one bounce: get_ray_color's blend of its own colour with the colours
+// its reflection / refraction children returned (ndt.c:402-429), in the reference's order.
+__device__ __forceinline__ void resolve_node(const double *blob, const SceneDesc &sd, const Workspace &ws, int specular, long long g)
+{
+    if (ws.depth_left[g] <= 0) return;
+    const int obj = ws.hit_obj[g];
+    if (obj < 0) return;                        // background node: colour and count already final
+    const int mw = sd.off_mat + 8 * obj;
+    const double hitr[3] = { blob[mw + 3], blob[mw + 4], blob[mw + 5] };
+    double c[3] = { ws.clr[0 * ws.cap + g], ws.clr[1 * ws.cap + g], ws.clr[2 * ws.cap + g] };
+    int cnt = ws.count[g];
+    const int refl = ws.child_refl[g];
+    if (refl != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refl >= 0) {
+            ref[0] = ws.clr[0 * ws.cap + refl]; ref[1] = ws.clr[1 * ws.cap + refl]; ref[2] = ws.clr[2 * ws.cap + refl];
+            cnt += ws.count[refl];
+        }
+        for (int k = 0; k < 3; ++k) {
+            if (specular) c[k] = (1 - hitr[k]) * (c[k]) + (hitr[k]) * ref[k];     // ndt.c:405-407
+            else c[k] += hitr[k] * ref[k];                                         // ndt.c:411-413
+        }
+    }
+    const int refr = ws.child_refr[g];
+    if (refr != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refr >= 0) {
+            ref[0] = ws.clr[0 * ws.cap + refr]; ref[1] = ws.clr[1 * ws.cap + refr]; ref[2] = ws.clr[2 * ws.cap + refr];
+            cnt += ws.count[refr];
+        }
+        for (int k = 0; k < 3; ++k) c[k] += (1.0 - hitr[k]) * ref[k];              // ndt.c:426-428
+    }
+    ws.clr[0 * ws.cap + g] = c[0];
+    ws.clr[1 * ws.cap + g] = c[1];
+    ws.clr[2 * ws.cap + g] = c[2];
+    ws.count[g] = cnt;
+}
+
+__global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc sd, Workspace ws, int specular, int level)
+{
+    const LevelRange lr = ws.levels[level];
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < lr.count; r += (long long)gridDim.x * blockDim.x)
+        resolve_node(blob, sd, ws, specular, lr.begin + r);
+}
+
+// get_pixel_color's adaptive loop (ndt.c:488-568) replayed on the one deterministic sample:
+// with samples == 1 the reference re-traces the identical ray k times, k decided by the
+// running-mean test below; the result is (c+...+c)/k and the k-fold ray count.
+__global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
+                                                       double *rgba, double *depth_out)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long weighted = 0ull;
+    if (g < rg.n_primary && ws.depth_left[g] > 0) {
+        long long out_idx = g;                          // list mode: one colour per sample
+        if (!rg.samples) {
+            const int tile = (int)(g >> 6), lane = (int)(g & 63);
+            const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
+            const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
+            out_idx = (long long)py * rg.width + px;    // dbl_image_set_pixel, image.c:126
+        }
+        const double l[4] = { ws.clr[0 * ws.cap + g], ws.clr[1 * ws.cap + g], ws.clr[2 * ws.cap + g],
+                              ws.hit_obj[g] >= 0 ? 1.0 : blob[sd.off_cam + 4 * N_ + 7] };
+        double t[4] = { 0.0, 0.0, 0.0, 0.0 };
+        const double max_diff = 1.0 / 256.0;
+        double clr_diff = 256;
+        int samples = 0;
+        // Every sample is the same colour l, so the reference's
+        //     clr_diff = max_c |t_c/(i-1) - (t_c+l_c)/i|        (t = l+l+...+l, i terms)
+        // is max_c(l_c)/(i(i-1)) up to rounding (relative error < 4 i^2 ulp: a difference of two
+        // quotients of an i-term running sum).  The six divisions are only spent when that
+        // estimate lies inside the error band around 1/256; otherwise the loop-exit decision
+        // is already certain and identical to the exact one.
+        const double gb0 = (fabs(l[1]) > fabs(l[2])) ? fabs(l[1]) : fabs(l[2]);
+        const double lmax = (fabs(l[0]) > gb0) ? fabs(l[0]) : gb0;
+        const bool finite = lmax <= 1.0e300;          // false for inf / nan: always take the exact path
+        for (int i = 0; i < 1 || (!rg.raw_samples && i < 10000 && clr_diff > max_diff); ++i) {
+            if (i > 1) {
+                const double ii = (double)i * (double)(i - 1);
+                const double est = lmax / ii;
+                const double band = 1.0e-15 * (8.0 * (double)i * (double)i) + 1.0e-12;
+                if (finite && est > max_diff * (1.0 + band)) {
+                    clr_diff = est;             // certainly still above the threshold: keep sampling
+                } else if (finite && est < max_diff * (1.0 - band)) {
+                    clr_diff = est;             // certainly converged: the loop ends here
+                } else {
+                    const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+                    const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+                    const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+                    const double gb = (dg > db) ? dg : db;      // MAX, image.h:31
+                    clr_diff = (dr > gb) ? dr : gb;
+                }
+            }
+            t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
+            samples += 1;
+        }
+        double *out = rgba + out_idx * 4;
+        out[0] = t[0] / samples;
+        out[1] = t[1] / samples;
+        out[2] = t[2] / samples;
+        out[3] = t[3] / samples;
+        if (depth_out) depth_out[out_idx] = ws.depth[g];       // ndt.c:753-756
+        weighted = (unsigned long long)samples * (unsigned long long)ws.count[g];
+    }
+    // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
+    // saturates near 90 atomics/us, and there are 32k wavefronts at 1080p)
+    for (int d = 32; d > 0; d >>= 1) weighted += __shfl_down(weighted, d, 64);
+    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), weighted);
+}
+
+// max_optic_depth <= 0: get_ray_color returns black without tracing (ndt.c:340)
+__global__ void k_fill_black(double *rgba, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    rgba[4 * i + 0] = 0.0; rgba[4 * i + 1] = 0.0; rgba[4 * i + 2] = 0.0; rgba[4 * i + 3] = 1.0;
+}
+
+// pixel_d2c, image.h:36-39
+void ndt_impl::launch_fill_black(hipStream_t s, double *rgba, long long n_pixels)
+{
+    hipLaunchKernelGGL(k_fill_black, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, rgba, n_pixels);
+}
+
+void ndt_impl::add_stats(ndt_render_stats &acc, const ndt_render_stats &st)
+{
+    acc.rays_primary += st.rays_primary;
+    acc.rays_secondary += st.rays_secondary;
+    acc.rays_shadow += st.rays_shadow;
+    acc.rays_ref_equiv += st.rays_ref_equiv;
+    if (st.levels > acc.levels) acc.levels = st.levels;
+    acc.trace_launches += st.trace_launches;
+    acc.trace_ms += st.trace_ms;
+    acc.frame_ms += st.frame_ms;
+    if (st.node_capacity > acc.node_capacity) acc.node_capacity = st.node_capacity;
+}
+
+// ------------------------------------------------------------------ render
+
+static hipEvent_t get_event(ndt_hip_ctx *ctx, size_t idx)
+{
+    while (ctx->ev_pool.size() <= idx) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(ev);
+    }
+    return ctx->ev_pool[idx];
+}
+
+static double wall_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// One pass of the ray pipeline over the primaries `rg` describes: primary rays, the bounce loop,
+// bottom-up resolve, per-primary colour (k_finish_pixels) into d_rgba.  Grid mode writes a
+// rows x width image, list mode one RGBA per sample.  max_depth > 0 (the callers handle -l 0).
+int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth)
+{
+    rg.want_depth = d_depth ? 1 : 0;
+    hipStream_t s = ctx->stream;
+    const long long n_primary = rg.n_primary;
+    const long long n_pixels = rg.samples ? (long long)rg.n_samples : (long long)rg.rows * rg.width;
+    long long cap = ctx->ws.cap, sh_cap = ctx->ws.sh_cap;
+    if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
+    const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
+    if (sh_cap < want_sh) sh_cap = want_sh;
+    if (getenv("NDT_HIP_TEST_SMALL_POOL") && ctx->ws.cap == 0) {
+        // tests only: a fresh context starts with a node pool that a reflective scene overflows, so that the
+        // overflow -> grow -> render-again path below is exercised (tests/test_gpu_parity.py)
+        cap = ((n_primary + 63) & ~63LL) + 64;
+    }
+
+    const NdtKernelTable *kt = ctx->kt;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
+        int rc = ensure_workspace(ctx, cap, sh_cap);
+        if (rc) return rc;
+        Workspace ws = ctx->ws;
+        size_t ev_n = 0;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+        std::vector<std::string> trace_dbg;
+        if (prof) {
+            // frame time = start of the frame's first kernel .. end of its last (their own dispatch timestamps)
+            ev_begin = get_event(ctx, ev_n++);
+            ev_end = get_event(ctx, ev_n++);
+        }
+        int *hc = ctx->h_counters;
+        if (prof && getenv("NDT_HIP_EXIT_PROBE"))
+            HIP_TRY(hipMemsetAsync(ws.exit_log, 0, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS * sizeof(unsigned int), s));
+        // The stream is never synchronised inside a frame: the range of every bounce is published
+        // on the device (k_level_step) and read there; the host only learns, from the mailbox,
+        // whether there is a next bounce to enqueue.  Bounce 0 = the primaries.
+        ws.mail = ctx->d_mail;
+        ws.mail_tag = ctx->d_mail_tag;
+        const unsigned long long tag = ++ctx->frame_tag;
+        const int n_seg = ctx->n_shadow_lights;
+        const int n_levels = rg.max_depth > 1 ? rg.max_depth : 1;      // a node spawns children only while depth_left > 1
+        int n_run = n_levels;                                           // bounces actually enqueued
+        LevelRange *hl = ctx->h_levels;
+        hl[0].begin = 0;
+        hl[0].count = rg.n_primary;
+        hl[0].seg_stride = (rg.n_primary + 63) & ~63LL;
+        hl[0].n_shadow = 0;
+        if ((long long)n_seg * hl[0].seg_stride > ws.sh_cap) {
+            sh_cap = (long long)n_seg * hl[0].seg_stride;
+            continue;
+        }
+        {
+            int slots = n_levels + 2;               // one trace launch per bounce + the primaries' own
+            if (slots > NDT_QUEUE_SLOTS) slots = NDT_QUEUE_SLOTS;
+            if (prof)
+                hipExtLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
+            else
+                hipLaunchKernelGGL(k_frame_init, dim3(8), dim3(256), 0, s, ws, rg.n_primary, hl[0], slots * NDT_QUEUE_INTS);
+        }
+        int queue_slot = 0;
+        int launches = 0;
+        kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+        auto traced = [&](TraceJob &tj, const std::string &what) -> int {
+            tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
+            static const bool exit_probe = getenv("NDT_HIP_EXIT_PROBE") != nullptr;
+            tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
+            if (prof) {
+                hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, a, b2);
+                trace_ev.push_back({ a, b2 });
+                trace_dbg.push_back(what);
+            } else {
+                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
+            }
+            ++launches;
+            return NDT_OK;
+        };
+        // closest-hit queries of the primaries: the only launch that is not shared
+        {
+            TraceJob tj{};
+            tj.n_seg = 0;
+            tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
+            tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
+            tj.begin = 0; tj.count = rg.n_primary; tj.levels = nullptr;
+            if ((rc = traced(tj, "closest 0"))) return rc;
+        }
+        long long upper = rg.n_primary;         // node count of the bounce
+        std::vector<long long> level_nodes;
+        // NDT_HIP_SHADE_PROBE=<k>: the k-th shade launch of the frame logs the life of each of its wavefronts
+        static const int shade_probe = getenv("NDT_HIP_SHADE_PROBE") ? atoi(getenv("NDT_HIP_SHADE_PROBE")) : -1;
+        int shade_launch = 0;
+        long long shade_probe_finish_waves = 0;         // wavefronts of the lighting part of the probed launch
+        long long shade_probe_emit_waves = 0;           // ... and of the shading part behind it (pair launches)
+        auto shade_ws = [&](long long finish_nodes, long long emit_nodes_behind = 0) {
+            Workspace w = ws;
+            if (shade_launch++ != shade_probe || !prof) {
+                w.shade_log = nullptr;
+            } else {
+                shade_probe_finish_waves = (finish_nodes + 255) / 256 * 4;
+                shade_probe_emit_waves = (emit_nodes_behind + 255) / 256 * 4;
+                (void)hipMemsetAsync(w.shade_log, 0, (size_t)2 * NDT_SHADE_LOG_WAVES * sizeof(unsigned int), s);
+            }
+            return w;
+        };
+        static const bool fuse_shade = !(getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR")));
+        int pending_finish = -1;                // bounce whose lighting has not been launched yet
+        long long pending_upper = 0;
+        for (int b = 0; b < n_levels; ++b) {
+            if (queue_slot + 1 > NDT_QUEUE_SLOTS || b + 1 > NDT_MAX_LEVELS)
+                return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
+            if (b > 0) {
+                // posted by k_level_step(b-1), which ran right after shade_emit(b-1)
+                const double t_wait = wall_s();
+                while (__atomic_load_n(&ctx->h_mail_tag[b], __ATOMIC_ACQUIRE) != tag) {
+                    if (wall_s() - t_wait > 30.0) {
+                        HIP_TRY(hipStreamSynchronize(s));
+                        if (__atomic_load_n(&ctx->h_mail_tag[b], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "bounce %d was never published", b);
+                    }
+                }
+                upper = ctx->h_mail[b].count;
+                if (upper <= 0) {
+                    n_run = b;
+                    break;
+                }
+            }
+            level_nodes.push_back(upper);
+            // hit points, shadow rays of this bounce, and the rays of the next bounce -- in the same launch as the
+            // lighting of the previous bounce, which is waiting for the shadow answers the last trace launch produced
+            if (pending_finish >= 0 && fuse_shade) {
+                kt->shade_pair(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper, upper), rg, pending_finish, pending_upper, upper);
+                pending_finish = -1;
+            } else {
+                if (pending_finish >= 0) {
+                    kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+                    pending_finish = -1;
+                }
+                kt->shade_emit(s, ctx->d_blob, ctx->sd, shade_ws(0), rg, b, upper);
+            }
+            hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
+            long long next_upper = 2 * upper;           // each node spawns at most two
+            if (next_upper > ws.cap) next_upper = ws.cap;
+            {
+                // ONE launch: shadow rays of bounce b + closest-hit rays of bounce b+1
+                TraceJob tj{};
+                tj.n_seg = n_seg;
+                tj.seg.o = ws.so; tj.seg.v = ws.sv; tj.seg.stride = ws.sh_cap; tj.seg.lim = ws.slim; tj.seg.valid = nullptr;
+                tj.seg.out_obj = ws.sobj; tj.seg.out_prim = ws.sprim;
+                tj.seg_count = NDT_SEG_COUNTERS(ws, b);
+                tj.seg_stride = (upper + 63) & ~63LL;           // sizes the grid only
+                tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
+                tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
+                tj.begin = 0;
+                tj.count = next_upper;                          // sizes the grid only
+                tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = b + 1;
+                if ((rc = traced(tj, "shadow " + std::to_string(b) + " + closest " + std::to_string(b + 1)))) return rc;
+            }
+            pending_finish = b;
+            pending_upper = upper;
+        }
+        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+        // bottom-up colour resolve, deepest bounce first (the primaries last)
+        {
+            for (int b = n_run; b-- > 0;) {
+                long long blocks = (level_nodes[b] + 255) / 256;
+                if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
+                hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws, rg.specular, b);
+            }
+        }
+        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                           rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+        if (prof)
+            hipExtLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, n_run, ctx->d_done, tag);
+        else
+            hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag);
+        HIP_TRY(hipGetLastError());
+        if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
+            // the bounce table only feeds the debug output
+            HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        {
+            // k_frame_done is the last kernel of the frame: once its tag is here, the image and the record are complete
+            const double t_wait = wall_s();
+            while (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) {
+                if (wall_s() - t_wait > 30.0) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "the frame never completed");
+                }
+            }
+        }
+        if (prof) HIP_TRY(hipEventSynchronize(ev_end));     // the closing kernel has run: its completion is at most microseconds away
+        hc[0] = (int)(long long)ctx->h_done[0];
+        hc[2] = (int)(long long)ctx->h_done[1];
+        hc[3] = (int)(long long)ctx->h_done[2];
+        const unsigned long long ref_rays = ctx->h_done[5];
+        if (hc[2] != 0) {
+            // a pool overflowed somewhere in the frame: grow it and render again
+            if (hc[2] & 1) cap *= 2;
+            if (hc[2] & 2) {
+                sh_cap *= 2;
+                if (sh_cap < hc[3]) sh_cap = hc[3];
+            }
+            continue;
+        }
+        const long long shadow_total = (long long)ctx->h_done[3];
+        const int levels_used = (int)ctx->h_done[4];
+        st = ndt_render_stats{};
+        st.rays_primary = n_pixels;
+        st.rays_secondary = (long long)hc[0] - rg.n_primary;
+        st.rays_shadow = shadow_total;
+        st.rays_ref_equiv = (long long)ref_rays;
+        st.levels = levels_used;
+        st.trace_launches = launches;
+        st.node_capacity = ws.cap;
+        if (prof) {
+            float ms = 0;
+            for (auto &pr : trace_ev) {
+                float m = 0;
+                HIP_TRY(hipEventElapsedTime(&m, pr.first, pr.second));
+                ms += m;
+            }
+            st.trace_ms = ms;
+            if (getenv("NDT_HIP_DEBUG_LEVELS")) {
+                for (int b = 0; b < levels_used; ++b)
+                    fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
+                unsigned long long d[160];
+                if (hipMemcpy(d, ws.dbg, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) d[4] = 0;
+                if (shade_probe >= 0 && ws.shade_log) {
+                    std::vector<unsigned int> log((size_t)2 * NDT_SHADE_LOG_WAVES);
+                    if (hipMemcpy(log.data(), ws.shade_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+                        unsigned int t0 = 0;
+                        bool any = false;
+                        for (int w = 0; w < NDT_SHADE_LOG_WAVES; ++w)
+                            if (log[2 * w + 1] && (!any || (int)(log[2 * w] - t0) < 0)) {
+                                t0 = log[2 * w];
+                                any = true;
+                            }
+                        for (int part = 0; part < 2; ++part) {
+                            // part 0: lighting (shade_finish) wavefronts, part 1: shading (shade_emit) wavefronts
+                            int hist[48] = { 0 }, n_w = 0;
+                            double sum = 0, longest = 0, last_start = 0, last_end = 0;
+                            for (long long w = 0; w < NDT_SHADE_LOG_WAVES; ++w) {
+                                const bool lighting = w < shade_probe_finish_waves;
+                                if (!log[2 * w + 1] || lighting != (part == 0)) continue;
+                                const double st_us = (log[2 * w] - t0) / 100.0, dur = (log[2 * w + 1] - log[2 * w]) / 100.0;
+                                ++n_w;
+                                sum += dur;
+                                if (dur > longest) longest = dur;
+                                if (st_us > last_start) last_start = st_us;
+                                if (st_us + dur > last_end) last_end = st_us + dur;
+                                const int bin = (int)(dur / 4.0);
+                                ++hist[bin > 47 ? 47 : bin];
+                            }
+                            if (!n_w) continue;
+                            std::string line;
+                            for (int bin = 0; bin < 48; ++bin)
+                                if (hist[bin]) {
+                                    char buf[48];
+                                    snprintf(buf, sizeof buf, " %d-%d:%d", bin * 4, bin * 4 + 4, hist[bin]);
+                                    line += buf;
+                                }
+                            fprintf(stderr, "ndt_hip: shade launch %d, %s: %d wavefronts, mean life %.1f us, longest %.1f us, last start at %.1f us, last end at %.1f us; lives per 4 us:%s\n",
+                                    shade_probe, part == 0 ? "lighting" : "shading", n_w, sum / n_w, longest, last_start, last_end, line.c_str());
+                        }
+                    }
+                }
+                if (getenv("NDT_HIP_EXIT_PROBE")) {
+                    // the life of every wavefront of every trace launch: when the queue runs dry (first exit), how long the
+                    // rest keeps going, and how much of that is the last wavefront's last batch
+                    std::vector<unsigned int> log((size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS);
+                    if (hipMemcpy(log.data(), ws.exit_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess)
+                        for (int l = 0; l < NDT_EXIT_LOG_LAUNCHES && l < launches; ++l) {
+                            const unsigned int *q = log.data() + (size_t)l * NDT_EXIT_LOG_WORDS;
+                            unsigned int t0 = 0;
+                            int n_w = 0;
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
+                                if (q[4 * w + 2]) {
+                                    if (!n_w || (int)(q[4 * w] - t0) < 0) t0 = q[4 * w];
+                                    ++n_w;
+                                }
+                            int hist[64] = { 0 };
+                            double first = 1e30, last = 0, last_batch = 0, start_spread = 0;
+                            int simd_of_wave[16][4] = { { 0 } };        // workgroup wavefront w -> SIMD it ran on
+                            int wpw = 12;                               // wavefronts per workgroup of this launch (logged by the kernel)
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
+                                if (q[4 * w + 2]) {
+                                    const double st_us = (q[4 * w] - t0) / 100.0, ex_us = (q[4 * w + 2] - t0) / 100.0;
+                                    wpw = (int)(q[4 * w + 3] >> 24) > 0 && (q[4 * w + 3] >> 24) <= 16 ? (int)(q[4 * w + 3] >> 24) : wpw;
+                                    ++simd_of_wave[w % wpw][(q[4 * w + 3] >> 4) & 3];
+                                    if (st_us > start_spread) start_spread = st_us;
+                                    if (ex_us < first) first = ex_us;
+                                    if (ex_us > last) {
+                                        last = ex_us;
+                                        last_batch = (q[4 * w + 2] - q[4 * w + 1]) / 100.0;
+                                    }
+                                    const int bin = (int)(ex_us / 16.0);
+                                    ++hist[bin > 63 ? 63 : bin];
+                                }
+                            std::string line;
+                            for (int bin = 0; bin < 64; ++bin)
+                                if (hist[bin]) {
+                                    char buf[48];
+                                    snprintf(buf, sizeof buf, " %d-%d:%d", bin * 16, bin * 16 + 16, hist[bin]);
+                                    line += buf;
+                                }
+                            if (l == 0) {
+                                std::string m;
+                                for (int w = 0; w < wpw; ++w) {
+                                    char buf[64];
+                                    snprintf(buf, sizeof buf, " w%d:%d/%d/%d/%d", w, simd_of_wave[w][0], simd_of_wave[w][1], simd_of_wave[w][2], simd_of_wave[w][3]);
+                                    m += buf;
+                                }
+                                fprintf(stderr, "ndt_hip: SIMD 0/1/2/3 of the workgroup's wavefronts (%d per workgroup):%s\n", wpw, m.c_str());
+                            }
+                            fprintf(stderr, "ndt_hip: trace launch %d: %d wavefronts start within %.1f us; first out of work at %.1f us, last at %.1f us (its last batch: %.1f us); exits per 16 us:%s\n",
+                                    l, n_w, start_spread, first, last, last_batch, line.c_str());
+                        }
+                }
+                if (d[4]) {
+                    // NDT_PHASE_TIMING builds only (make -C ndt_amd/csrc timing)
+                    fprintf(stderr, "ndt_hip: wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
+                    fprintf(stderr, "ndt_hip: per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
+                            d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
+                    fprintf(stderr, "ndt_hip: batch time inside trace_kd (100 MHz wall clock): closest max %.1f us mean %.1f us, shadow max %.1f us mean %.1f us\n",
+                            d[40] / 100.0, d[44] ? d[42] / 100.0 / d[44] : 0.0, d[41] / 100.0, d[45] ? d[43] / 100.0 / d[45] : 0.0);
+                    fprintf(stderr, "ndt_hip: per-ray maxima: %llu node visits, %llu gates, %llu intersections; per-batch maxima: %llu T, %llu G, %llu I iterations\n",
+                            d[46], d[47], d[48], d[49], d[50], d[51]);
+                    if (d[58])
+                        fprintf(stderr, "ndt_hip: shade_emit per wavefront (wall-clock ticks, mean over %llu): load+isect %.0f, light tests %.0f, segment reserve %.0f, shadow stores %.0f, spawn %.0f; slowest wavefront %llu\n",
+                                d[58], (double)d[52] / d[58], (double)d[53] / d[58], (double)d[54] / d[58], (double)d[55] / d[58], (double)d[56] / d[58], d[59]);
+                    for (int kind = 0; kind < 2; ++kind) {
+                        const unsigned long long *q = d + 16 + 8 * kind;
+                        fprintf(stderr, "ndt_hip: loop occupancy (%s rays): T %.1f%% of %llu iters, G %.1f%% of %llu, I %.1f%% of %llu\n",
+                                kind ? "shadow" : "closest", q[0] ? 100.0 * q[1] / (64.0 * q[0]) : 0.0, q[0],
+                                q[2] ? 100.0 * q[3] / (64.0 * q[2]) : 0.0, q[2], q[4] ? 100.0 * q[5] / (64.0 * q[4]) : 0.0, q[4]);
+                        if (q[4])
+                            fprintf(stderr, "ndt_hip:    I iterations execute %.2f primitive types on average; the commonest type holds %.1f of %.1f active lanes\n",
+                                    (double)q[6] / q[4], (double)q[7] / q[4], (double)q[5] / q[4]);
+                    }
+                }
+                for (size_t i = 0; i < trace_ev.size(); ++i) {
+                    float m = 0;
+                    (void)hipEventElapsedTime(&m, trace_ev[i].first, trace_ev[i].second);
+                    fprintf(stderr, "ndt_hip: trace launch %zu: %.3f ms (%s)\n", i, m, trace_dbg[i].c_str());
+                }
+            }
+            float fm = 0;
+            HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
+            st.frame_ms = fm;
+        }
+        return NDT_OK;
+    }
+    return fail(NDT_E_NOMEM, "ray-tree workspace kept overflowing");
+}
+

@@ -13,6 +13,9 @@
 #include "ndt_kernels.hpp"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #ifndef NDT_DIMS
 #error "compile with -DNDT_DIMS=<3..8>"
@@ -452,7 +455,7 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
             job.exit_log[4 * w] = probe_start;
             job.exit_log[4 * w + 1] = probe_batch;
             job.exit_log[4 * w + 2] = (unsigned int)wall_clock64() | 1u;
-            job.exit_log[4 * w + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], ...
+            job.exit_log[4 * w + 3] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffffu) | ((blockDim.x / 64) << 24);   // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]; [31:24] wavefronts per workgroup
         }
     }
 #ifdef NDT_PHASE_TIMING
@@ -479,15 +482,24 @@ static int env_int(const char *name, int def)
     return (e && *e) ? atoi(e) : def;
 }
 
+// Workgroups of `kernel` that are resident on the device at once (occupancy x CUs).  Asked once per (device, kernel
+// variant, workgroup size, LDS bytes) and remembered: a frame has five trace launches, the query takes longer than a
+// launch, and contexts on several threads (ndt_hip -j K) share the table.
 template <typename K> static int resident_blocks(K kernel, int block, size_t lds)
 {
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void *, int, size_t>, int> known;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_tuple(dev, reinterpret_cast<const void *>(kernel), block, lds);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(key);
+    if (it != known.end()) return it->second;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    int cus = 256, v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    known[key] = per_cu * cus;
     return per_cu * cus;
 }
 
@@ -546,19 +558,16 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
             if (nb > res) nb = res;
             NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true, true>), nb, lstack_block, lds_stack);
         } else if (mask_words <= 1) {
-            static int res = 0;
-            if (!res) res = resident_blocks(k_trace<1, true>, block, lds);
+            const int res = resident_blocks(k_trace<1, true>, block, lds);
             if (blocks > res) blocks = res;
             NDT_LAUNCH_TRACE((k_trace<1, true>), blocks, block, lds);
         } else {
-            static int res = 0;
-            if (!res) res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true>, block, lds);
+            const int res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true>, block, lds);
             if (blocks > res) blocks = res;
             NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true>), blocks, block, lds);
         }
     } else {
-        static int res = 0;
-        if (!res) res = resident_blocks(k_trace<0, false>, block, 0);
+        const int res = resident_blocks(k_trace<0, false>, block, 0);
         if (blocks > res) blocks = res;
         const long long max_blocks = ws.mask_slab_lanes / block;
         if (blocks > max_blocks) blocks = max_blocks;

@@ -110,7 +110,7 @@ struct TraceJob {
     int tail_solo;              // the last this-many batches of every queue shard go to one wavefront per SIMD only (k_trace)
     unsigned int *exit_log;     // NDT_HIP_EXIT_PROBE: {start, start of the last batch, exit} per wavefront (100 MHz clock, low words)
 };
-#define NDT_EXIT_LOG_WORDS 12288    /* per launch: 3 words x 4096 wavefronts */
+#define NDT_EXIT_LOG_WORDS 65536    /* per launch: 4 words {start, last batch, exit, HW_ID} x 16384 wavefronts */
 #define NDT_EXIT_LOG_LAUNCHES 6
 #define NDT_SHADE_LOG_WAVES 131072  /* wavefronts the shade probe has slots for */
 

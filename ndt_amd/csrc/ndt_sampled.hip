@@ -1,0 +1,192 @@
+// ndt_sampled.hip -- `-n samples` > 1, depth of field and area lights (ndt.c:116-147, 470-568) on top of render_pass.
+#include "ndt_ctx.hpp"
+
+// ------------------------------------------------------------------ -n samples > 1 (ndt.c:470-568)
+//
+// Jittered samples inside the pixel + a lens sample per ray, the adaptive loop on top: at least
+// `samples` samples per pixel, then more while the running mean still moves by more than 1/256
+// (at most 10000).  The reference draws from one global drand48 stream in pixel order, which no
+// parallel renderer can follow; here every (pixel, sample) has its own counter-based stream, so the
+// image is reproducible and independent of sharding, and parity with the reference is statistical
+// (tests compare against the oracle, which follows the reference's stream exactly).
+// Round r renders sample r of every pixel that is still sampling, through the pipeline in list mode.
+
+// the random stream of sample `round` of image pixel `pixel`
+__device__ __forceinline__ unsigned long long ns_sample_key(unsigned long long pixel, unsigned int round)
+{
+    return ndt_rng_mix(pixel * 0x100000001b3ull + round);
+}
+
+// sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
+// (`per` consecutive samples per pixel in one pass: sample a*per + r is the pixel's sample number round + r)
+__global__ void k_ns_samples(const int *active, int n_active, int per, int width, int row_begin, int row_step, unsigned int round0,
+                             double aperture, int jitter, double *samples, unsigned long long *keys)
+{
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (long long)n_active * per) return;
+    const int pix = active[a / per];
+    const unsigned int round = round0 + (unsigned int)(a % per);
+    const int l = pix / width, i = pix % width;
+    const int j = row_begin + l * row_step;
+    const unsigned long long id = (unsigned long long)j * (unsigned long long)width + (unsigned long long)i;
+    const unsigned long long key = ns_sample_key(id, round);
+    keys[a] = key;
+    double dx = 0.0, dy = 0.0, ax = 0.0, ay = 0.0;
+    if (jitter) {       // -n > 1 only (ndt.c:505, 528); with -n 1 the area lights are all that is random
+        dx = ndt_rng_uniform(key, 1000);
+        dy = ndt_rng_uniform(key, 1001);
+        unsigned int k = 1002;
+        do {        // reject samples outside the unit disk
+            ax = 2 * ndt_rng_uniform(key, k) - 1.0;
+            ay = 2 * ndt_rng_uniform(key, k + 1) - 1.0;
+            k += 2;
+        } while (ax * ax + ay * ay > 1.0 && k < 1064);
+    }
+    double *q = samples + 4ll * a;
+    q[0] = i + dx;          // x = orig_x + dx/width
+    q[1] = j - dy;          // y = orig_y + dy/height, and y grows upwards
+    q[2] = ax * aperture;
+    q[3] = ay * aperture;
+}
+
+// get_pixel_color's loop body after the sample has been traced (ndt.c:553-567), and its continuation test
+// A pass may have rendered `per` samples ahead for every pixel; they are consumed one by one exactly as the
+// loop would, and the ones after the loop's exit are dropped (they were speculation: fewer, fuller passes).
+__global__ void k_ns_accumulate(const int *active, int n_active, int per, const double *colours, unsigned int round0, int min_samples,
+                                double *acc, int *taken, int *next, int *next_count)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = a < n_active;
+    const int pix = in_range ? active[a] : 0;
+    double *t = acc + 5ll * pix;            // t_clr rgba + clr_diff
+    double clr_diff = in_range ? t[4] : 0.0;
+    bool go_on = in_range;
+    int used = 0;
+    for (int r = 0; r < per && go_on; ++r) {
+        const double *l = colours + 4ll * ((long long)a * per + r);
+        const int i = (int)round0 + r;
+        if (i > 1) {
+            const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
+            const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
+            const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
+            const double gb = (dg > db) ? dg : db;
+            clr_diff = (dr > gb) ? dr : gb;
+        }
+        t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
+        ++used;
+        const int done = i + 1;
+        go_on = done < min_samples || (done < 10000 && clr_diff > 1.0 / 256.0);
+    }
+    if (in_range) {
+        t[4] = clr_diff;
+        taken[pix] += used;
+    }
+    const int slot = wave_append(next_count, go_on);
+    if (go_on) next[slot] = pix;
+}
+
+__global__ void k_ns_init(double *acc, int *active, int *taken, long long n_pixels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    double *t = acc + 5 * i;
+    t[0] = t[1] = t[2] = t[3] = 0.0;
+    t[4] = 256.0;
+    active[i] = (int)i;
+    taken[i] = 0;
+}
+
+__global__ void k_ns_finish(const double *acc, const int *taken, double *rgba, long long n_pixels, unsigned long long *used_total)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long used = 0;
+    if (i < n_pixels) {
+        const int n = taken[i] > 0 ? taken[i] : 1;
+        for (int c = 0; c < 4; ++c) rgba[4 * i + c] = acc[5 * i + c] / n;
+        used = (unsigned long long)taken[i];
+    }
+    for (int d = 32; d > 0; d >>= 1) used += __shfl_down(used, d, 64);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(used_total, used);
+}
+
+int ndt_impl::render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total)
+{
+    hipStream_t s = ctx->stream;
+    const int W = p->width, H = p->height;
+    const int rows = ndt_hip_shard_rows(H, p->row_begin, p->row_step);
+    const long long n_pixels = (long long)rows * W;
+    if (n_pixels > 0x3fffffffLL) return fail(NDT_E_UNSUPPORTED, "image too large for one call");
+    AaBuffers buf(ctx);
+    int rc;
+    double *acc = nullptr, *samples = nullptr, *colours = nullptr;
+    unsigned long long *keys = nullptr;
+    int *list[2] = { nullptr, nullptr }, *taken = nullptr, *counter = nullptr;
+    if ((rc = buf.get(&acc, (size_t)n_pixels * 5))) return rc;
+    if ((rc = buf.get(&list[0], (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&list[1], (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&taken, (size_t)n_pixels))) return rc;
+    if ((rc = buf.get(&counter, 1))) return rc;
+    const unsigned g_all = (unsigned)((n_pixels + 255) / 256);
+    hipLaunchKernelGGL(k_ns_init, dim3(g_all), dim3(256), 0, s, acc, list[0], taken, n_pixels);
+    int n_active = (int)n_pixels;
+    // samples per pixel and pass: the first `samples` are certain to be needed; after that the loop may stop at
+    // any sample, so passes speculate further ahead the fewer pixels are left (about 4 M primaries per pass)
+    const long long per_pass = 4ll << 20;
+    size_t cap_samples = 0;
+    int flip = 0;
+    for (unsigned int round = 0; n_active > 0 && round < 10000;) {
+        long long per = round < (unsigned int)p->samples ? (long long)p->samples - round : per_pass / n_active;
+        if (per > per_pass / n_active) per = per_pass / n_active;
+        // ... but never more than have been taken already: the waste stays below a factor of two
+        if (round >= (unsigned int)p->samples && per > (long long)(round < 2 ? 1 : round)) per = round < 2 ? 1 : round;
+        if (per < 1) per = 1;
+        if (per > 64) per = 64;
+        if (round + per > 10000) per = 10000 - round;
+        const long long n_s = (long long)n_active * per;
+        if ((size_t)n_s > cap_samples) {
+            cap_samples = (size_t)n_s;
+            if ((rc = buf.get(&samples, cap_samples * 4))) return rc;
+            if ((rc = buf.get(&colours, cap_samples * 4))) return rc;
+            if ((rc = buf.get(&keys, cap_samples + 64))) return rc;
+        }
+        const unsigned g_act = (unsigned)((n_active + 255) / 256);
+        hipLaunchKernelGGL(k_ns_samples, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, list[flip], n_active, (int)per, W,
+                           p->row_begin, p->row_step, round, ctx->aperture_radius, p->samples > 1 ? 1 : 0, samples, keys);
+        RenderGeom gs{};
+        gs.samples = samples;
+        gs.n_samples = (int)n_s;
+        gs.n_primary = (int)((n_s + 63) & ~63LL);
+        gs.width = (int)n_s;
+        gs.rows = 1;
+        gs.max_depth = p->max_optic_depth;
+        gs.specular = p->specular ? 1 : 0;
+        gs.img_w = W;
+        gs.img_h = H;
+        gs.aspect_w = W;
+        gs.aspect_h = H;
+        gs.eye = 1;
+        gs.lens = 1;
+        gs.raw_samples = 1;
+        gs.sample_keys = keys;
+        ndt_render_stats st{};
+        if ((rc = render_pass(ctx, gs, p->profile != 0, colours, st))) return rc;
+        add_stats(total, st);
+        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ns_accumulate, dim3(g_act), dim3(256), 0, s, list[flip], n_active, (int)per, colours, round, p->samples,
+                           acc, taken, list[flip ^ 1], counter);
+        HIP_TRY(hipMemcpyAsync(&n_active, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        flip ^= 1;
+        round += (unsigned int)per;
+    }
+    unsigned long long *used_total = nullptr, used_host = 0;
+    if ((rc = buf.get(&used_total, 1))) return rc;
+    HIP_TRY(hipMemsetAsync(used_total, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_ns_finish, dim3(g_all), dim3(256), 0, s, acc, taken, (double *)d_rgba, n_pixels, used_total);
+    HIP_TRY(hipMemcpyAsync(&used_host, used_total, sizeof(used_host), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    total.aa_samples = (long long)used_host;       // samples the adaptive loop consumed (the rays_* counts include the speculation)
+    return NDT_OK;
+}
+

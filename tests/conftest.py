@@ -116,8 +116,13 @@ SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4
                "c5_hypercube5d", "c5_hypercube6d", "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror",
                "zoo5d_f2", "zoo6d"]
 KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d", "c5_hypercube6d",
-             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d"]
-FULL_CASES = ["c2_balls4d_1080p", "c3_random4d_1080p"]
+             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d",
+             # 8192 queries each, half of them aimed at the items of every kd leaf: the global-memory tier
+             "kat_hypercube6d", "kat_hypercube7d", "kat_hypercube8d"]
+# every BASELINE config at its stated size, 8-bit like the reference's PNG: configs[0] 256x256, [1] and [2] 1920x1080,
+# [3]'s 3840x2160 frame, [4]'s 6-D .. 8-D sweep at 1920x1080
+FULL_CASES = ["c1_hypercube3d_256", "c2_balls4d_1080p", "c3_random4d_1080p", "c4_random4d_4k", "c5_hypercube6d_1080p",
+              "c5_hypercube7d_1080p", "c5_hypercube8d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
 SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3"]   # -n samples > 1 and / or area lights

@@ -62,6 +62,26 @@ CASES = {
                              share_scene="c2_balls4d"),
     "c3_random4d_1080p": dict(scene="random", dims=4, res=(1920, 1080), depth=4, fb=False, rgba8=True, kat=0,
                               share_scene="c3_random4d"),
+    # every BASELINE config at its stated size (8-bit, like the two above): configs[0] 256x256, configs[3]'s 3840x2160
+    # frame, configs[4]'s 6-D .. 8-D sweep at 1920x1080
+    "c1_hypercube3d_256": dict(scene="hypercube", dims=3, res=(256, 256), depth=128, fb=False, rgba8=True, kat=0,
+                               share_scene="c1_hypercube3d"),
+    "c4_random4d_4k": dict(scene="random", dims=4, res=(3840, 2160), depth=4, fb=False, rgba8=True, kat=0,
+                           share_scene="c3_random4d"),
+    "c5_hypercube6d_1080p": dict(scene="hypercube", dims=6, res=(1920, 1080), depth=128, fb=False, rgba8=True, kat=0,
+                                 share_scene="c5_hypercube6d"),
+    "c5_hypercube7d_1080p": dict(scene="hypercube", dims=7, res=(1920, 1080), depth=128, fb=False, rgba8=True, kat=0,
+                                 share_scene="c5_hypercube7d"),
+    "c5_hypercube8d_1080p": dict(scene="hypercube", dims=8, res=(1920, 1080), depth=128, fb=False, rgba8=True, kat=0,
+                                 share_scene="c5_hypercube8d"),
+    # known answers only (an 8x8 render that is not kept): 8192 trace_kd queries each for the scenes of the
+    # global-memory tier, half of them aimed at the items of every kd leaf (make_kat_rays, aimed=True)
+    "kat_hypercube6d": dict(scene="hypercube", dims=6, res=(8, 8), depth=2, fb=False, kat=8192, kat_aimed=True,
+                            share_scene="c5_hypercube6d"),
+    "kat_hypercube7d": dict(scene="hypercube", dims=7, res=(8, 8), depth=2, fb=False, kat=8192, kat_aimed=True,
+                            share_scene="c5_hypercube7d"),
+    "kat_hypercube8d": dict(scene="hypercube", dims=8, res=(8, 8), depth=2, fb=False, kat=8192, kat_aimed=True,
+                            share_scene="c5_hypercube8d"),
     # Whitted's recursive anti-aliasing (-a diff,depth): fb = the resampled image in doubles, produced by the
     # reference's own render_line + resample_pixel (the shim's --aa mode); reference defaults are 20,4
     "aa_c3_random4d": dict(scene="random", dims=4, res=(64, 36), depth=4, fb=True, kat=0, aa=(20, 4),
@@ -117,8 +137,51 @@ def run_shim(args):
     return info
 
 
-def make_kat_rays(fs, n, seed):
-    """Seeded query rays: camera-like, interior random, and shadow-like with limits."""
+def leaf_targets(fs, rng, n):
+    """n points inside the bounding spheres of kd-leaf items, walking the leaves round-robin so that every leaf
+    (and, as n allows, every item of it) is aimed at."""
+    leaves = [k for k in fs.kd_nodes if k["dim"] < 0 and k["num"] > 0]
+    out = []
+    turn = 0
+    while len(out) < n and leaves:
+        for k in leaves:
+            if len(out) >= n:
+                break
+            item = fs.leaf_refs[k["first"] + turn % k["num"]]
+            o = fs.objects[item]
+            c = fs.vec(o["bounds_center_off"])
+            r = o["bounds_radius"] if o["bounds_radius"] > 0 else 0.5
+            u = rng.standard_normal(fs.dims)
+            u /= np.linalg.norm(u)
+            out.append(c + u * r * rng.random() ** (1.0 / fs.dims))
+        turn += 1
+    return out
+
+
+def make_kat_rays(fs, n, seed, aimed=False):
+    """Seeded query rays: camera-like, interior random, and shadow-like with limits.  aimed=True: the second half of
+    the rays go for points inside the bounding spheres of the items of every kd leaf (same four kinds of ray)."""
+    if aimed:
+        head = make_kat_rays(fs, n // 2, seed)
+        rng = np.random.default_rng(seed + 77)
+        d = fs.dims
+        cam = fs.vec(fs.cam["pos"])
+        lo, hi = fs.vec(fs.bb["lower"]), fs.vec(fs.bb["upper"])
+        if not np.all(np.isfinite(lo)) or np.any(lo > hi):
+            lo, hi = -10 * np.ones(d), 10 * np.ones(d)
+        tail = np.zeros((n - n // 2, 2 * d + 1))
+        for i, tgt in enumerate(leaf_targets(fs, rng, n - n // 2)):
+            kind = i % 4
+            o = cam if kind == 0 else lo - 1 + rng.random(d) * (hi - lo + 2)
+            v = tgt - o
+            nv = np.linalg.norm(v)
+            if nv < 1e-9:
+                v, nv = np.ones(d), np.sqrt(d)
+            lim = -1.0 if kind < 2 else (0.0 if kind == 2 else float(nv) * rng.uniform(0.3, 1.2))
+            tail[i, :d] = o
+            tail[i, d:2 * d] = v / nv
+            tail[i, 2 * d] = lim
+        return np.concatenate([head, tail])
     rng = np.random.default_rng(seed)
     d = fs.dims
     cam = fs.vec(fs.cam["pos"])
@@ -205,7 +268,7 @@ def generate(name, case):
             args[args.index("--threads") + 1] = "1"
             meta["samples"] = case["samples"]
         if case["kat"]:
-            rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"])
+            rays = make_kat_rays(fs, case["kat"], seed=1234 + case["dims"], aimed=bool(case.get("kat_aimed")))
             rays.tofile(os.path.join(tmp, "rays.bin"))
             args += ["--rays-in", os.path.join(tmp, "rays.bin"), "--rays-out", os.path.join(tmp, "kat.bin")]
         meta.update(run_shim(args))
