@@ -11,11 +11,12 @@ Workload (N=1): BASELINE.json configs[2] -- scenes/random.c, 4-D, 1920x1080, `-l
 object-plugin set + kd-tree -- the configuration the north_star's target is quoted on.  The
 scene is the committed fixture tests/golden/c3_random4d.ndtscene.gz (flattened from the
 compiled reference), i.e. synthetic data.
-N>1: the same scene and camera; the frame grows to N x (1920x1080) pixels at the same aspect
-ratio (N=4 is exactly configs[3]'s 3840x2160), rows are dealt cyclically to the ranks like the
-reference's MPI_ROW mode (ndt.c:812-820) and one RCCL gather over xGMI assembles the final
-8-bit image on rank 0 (--gather f64: the double framebuffer) -- per-GPU work is fixed, so
-"scaling": "weak".
+N>1: BASELINE.json configs[3] -- the same scene and camera at 3840x2160 for EVERY N > 1, rows
+dealt cyclically to the ranks like the reference's MPI_ROW mode (ndt.c:812-820), one RCCL
+gather over xGMI assembling the final 8-bit image on rank 0 (--gather f64: the double
+framebuffer): total work is fixed as N grows, "scaling": "strong"; rank 0 also times the whole
+3840x2160 frame on its one GPU after the run (`strong_reference`), the time the N-GPU frame is
+to be compared with.  `--scaling weak` keeps per-GPU work fixed instead (N x 1080p pixels).
 
 `value` counts rays ACTUALLY traced on the GPUs (one trace_kd query each).  The reference
 re-traces every pixel's identical ray tree k = 3..18 times (adaptive loop, ndt.c:488; SURVEY
@@ -53,8 +54,11 @@ WORKLOADS = {
 }
 
 
-def frame_size(n_gpus):
-    """N x 1080p pixels at 16:9, multiples of 8 (N=1: 1920x1080, N=4: 3840x2160)."""
+def frame_size(n_gpus, scaling="strong"):
+    """strong: configs[2]'s 1920x1080 on one GPU, configs[3]'s 3840x2160 on any N > 1.
+    weak: N x 1080p pixels at 16:9, multiples of 8 (N=1: 1920x1080, N=4: 3840x2160)."""
+    if scaling == "strong":
+        return (1920, 1080) if n_gpus == 1 else (3840, 2160)
     s = math.sqrt(n_gpus)
     w = int(round(1920 * s / 8.0)) * 8
     h = int(round(1080 * s / 8.0)) * 8
@@ -80,12 +84,15 @@ def pmc_traffic(workload, width, height):
 def cpu_baseline(workload, width, height, depth, threads=16):
     """Time the reference itself (oracle/_ref, built from /root/reference by oracle/Makefile) on
     the host cores of this box, for the same frame.  Falls back to the oracle port if the
-    reference build did not travel."""
+    reference build did not travel.  threads=1: the reference's single-thread rate (SURVEY 8d asks for both), on a
+    quarter-size frame (half the width, half the height: about a quarter of the rays) so that it stays a bounded sample."""
     fixture, _, scene_so, dims, _ = WORKLOADS[workload]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box owns a 16-core share of the host; the reference's pthread path also stops
     # scaling there (per-ray calloc/free + row imbalance: 256 threads are 2x SLOWER than 16)
     cores = min(avail, threads)
+    if threads == 1:
+        width, height = width // 2, height // 2
     shim = os.path.join(ROOT, "oracle", "_ref", "ndt_ref_shim")
     if os.path.exists(shim):
         cmd = [shim, "--objects", os.path.join(ROOT, "oracle", "_ref", "objects"),
@@ -131,6 +138,9 @@ def main():
     ap.add_argument("--workload", default="random4d", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="pthreads for the reference CPU baseline")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = BASELINE configs[3]'s 3840x2160 frame at every N (total work fixed); weak = N x 1080p "
+                         "pixels (per-GPU work fixed)")
     ap.add_argument("--gather", default="rgba8", choices=["f64", "rgba8"],
                     help="what the image gather moves: rgba8 = the final 8-bit image (pixel_d2c on the device, what the "
                          "reference writes to disk), f64 = the double framebuffer (8x the bytes over xGMI)")
@@ -179,7 +189,9 @@ def main():
 
     fixture, depth, _, dims, cfg_idx = WORKLOADS[args.workload]
     fs = load_scene(os.path.join(ROOT, "tests", "golden", fixture + ".ndtscene.gz"))
-    width, height = frame_size(world)
+    width, height = frame_size(world, args.scaling)
+    if world > 1 and args.scaling == "strong":
+        cfg_idx = 3 if args.workload == "random4d" else cfg_idx
     gpu = NdtHip(local_rank)
     gpu.upload_scene(fs)
 
@@ -311,7 +323,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -349,8 +361,31 @@ def main():
                           "%s timed step" % ("" if every == 1 else "%d-th" % every),
             },
         }
+        if world == 1:
+            # what a caller of ndt_hip_render_rgba8 waits for: render + pixel_d2c on the device + the 4-bytes-per-pixel
+            # copy to host memory (the reference's "rendering took" ends with the pixels in host memory)
+            gpu.render_rgba8(width, height, depth)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gpu.render_rgba8(width, height, depth)
+            line["ms_per_step_host_rgba8"] = (time.perf_counter() - t1) / 5 * 1e3
+        elif args.scaling == "strong" and not rehearsal:
+            # the time this frame takes on ONE GPU (rank 0's, alone: the other ranks wait at the barrier below)
+            whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            gpu.render_device(whole.data_ptr(), width, height, depth)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gpu.render_device(whole.data_ptr(), width, height, depth)
+            gpu.synchronize()
+            one = (time.perf_counter() - t1) / 5 * 1e3
+            line["strong_reference"] = {"ms_one_gpu_same_frame": one, "speedup": one / line["ms_per_step"],
+                                        "what": "the whole %dx%d frame rendered on rank 0's GPU alone (image left in HBM), "
+                                                "5 frames after the timed region" % (width, height)}
+            del whole
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, width, height, depth, args.cpu_threads)
+            line["cpu_baseline_t1"] = cpu_baseline(args.workload, width, height, depth, 1)
         print(json.dumps(line), flush=True)
     if args.verify and multi and rank == 0:
         whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")

@@ -247,6 +247,32 @@ int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n, const double *o, const doubl
  * d_rgba8: device, n_pixels*4 bytes. */
 int ndt_hip_quantize_device(ndt_hip_ctx *ctx, const void *d_rgba, void *d_rgba8, int64_t n_pixels);
 
+/* What the calls that deliver a finished image write: the double framebuffer (4 doubles per pixel, image.c:126) or the
+ * bytes the reference stores at save time (pixel_d2c on every channel, image.h:36-39, image.c:648-651: 4 bytes per pixel). */
+enum ndt_image_format { NDT_IMAGE_F64 = 0, NDT_IMAGE_RGBA8 = 1 };
+
+/* render_image followed by the reference's save-time quantisation, on the device: `rgba8` (host) receives
+ * rows*width*4 bytes.  An eighth of ndt_hip_render's bytes cross PCIe. */
+int ndt_hip_render_rgba8(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats);
+
+/* ONE frame over several contexts -- one per GPU of the node, or several on one GPU -- called from one host thread.
+ * The rows `p` selects are dealt cyclically to the contexts exactly as the reference deals rows to MPI ranks in
+ * MPI_MODE_ROW (ndt.c:812-820: row_start = rank, row_step = size): context k renders rows
+ * p->row_begin + (k + i*n_ctx)*p->row_step.  Every context must hold the same uploaded scene.  Each device pushes
+ * its finished rows straight into the assembled image on ctxs[0]'s device (peer stores over xGMI; through a staging
+ * copy where peer access is unavailable) -- the reference instead sum-reduces full-size zero-padded images up a
+ * binary tree (mpi_collect_image, ndt.c:1277-1309).  `format` = ndt_image_format.  _device: `d_out` is memory of
+ * ctxs[0]'s device; plain: `out` is host memory.  stats: ray counts summed over the contexts, times = the slowest's.
+ * Not with a depth map.  Returns when the image is complete. */
+int ndt_hip_render_multi_device(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_render_params *p, int32_t format,
+                                void *d_out, ndt_render_stats *stats);
+int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_render_params *p, int32_t format,
+                         void *out, ndt_render_stats *stats);
+
+/* HIP devices this process sees (0 without a GPU), and the device a context lives on. */
+int ndt_hip_device_count(void);
+int ndt_hip_device(ndt_hip_ctx *ctx);
+
 /* Number of rows a (row_begin,row_step) shard of a `height`-row image holds. */
 int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step);
 

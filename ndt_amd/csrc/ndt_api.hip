@@ -81,9 +81,12 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
 extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
 {
     if (!ctx) return NDT_OK;
+    worker_stop(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
+    if (ctx->d_shard) (void)hipFree(ctx->d_shard);
+    if (ctx->d_image) (void)hipFree(ctx->d_image);
     for (auto &slot : ctx->pool)
         if (slot.first) (void)hipFree(slot.first);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,8 @@
 #include "ndt_kernels.hpp"
 
 namespace ndt_impl {
+
+struct CtxWorker;       // ndt_multi.hip: the thread that drives a context inside a multi-context render
 
 // sets the calling thread's ndt_hip_last_error() text and returns `code`
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -62,6 +65,11 @@ struct ndt_hip_ctx {
     int ws_nseg = 0;
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
+    void *d_shard = nullptr;        // ndt_hip_render_multi: this context's rows before they are pushed into the frame
+    size_t d_shard_bytes = 0;
+    void *d_image = nullptr;        // ndt_hip_render_multi (host output): the assembled frame on the first context's device
+    size_t d_image_bytes = 0;
+    ndt_impl::CtxWorker *worker = nullptr;
     int *h_counters = nullptr;      // pinned
     LevelRange *h_levels = nullptr; // pinned, NDT_MAX_LEVELS + 1
     LevelRange *h_mail = nullptr;   // mapped + coherent: bounce ranges posted by k_level_step while the frame runs
@@ -93,6 +101,9 @@ int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap);
 int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth = nullptr);
 void launch_fill_black(hipStream_t s, double *rgba, long long n_pixels);
 void add_stats(ndt_render_stats &acc, const ndt_render_stats &st);
+
+// ndt_multi.hip
+void worker_stop(ndt_hip_ctx *ctx);
 
 // ndt_aa.hip / ndt_sampled.hip
 int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);

@@ -1045,6 +1045,10 @@ __global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, Scene
     }
 }
 
+// ------------------------------------------------------------------ the streaming frame kernel
+
+#include "ndt_stream.hpp"
+
 // ------------------------------------------------------------------ hit points for the trace_kd batch API
 
 __global__ void __launch_bounds__(256) k_hitpoints(const double *blob, SceneDesc sd, const double *o, const double *v,
@@ -1105,6 +1109,6 @@ extern "C" const NdtKernelTable *NDT_CAT(ndt_kernel_table_, NDT_DIMS)()
 {
     using namespace NDT_CAT(ndt_d, NDT_DIMS);
     static const NdtKernelTable table = { NDT_DIMS, launch_primary, launch_trace, launch_shade_emit, launch_shade_finish,
-                                          launch_shade_pair, launch_hitpoints };
+                                          launch_shade_pair, launch_hitpoints, launch_frame_stream };
     return &table;
 }

@@ -115,6 +115,41 @@ struct TraceJob {
 #define NDT_SHADE_LOG_WAVES 131072  /* wavefronts the shade probe has slots for */
 
 
+// ------------------------------------------------------------------ the streaming frame kernel (ndt_stream.hpp)
+//
+// One persistent launch renders the whole ray tree of a frame: wavefronts pull typed work items -- a batch of 64
+// nodes to trace and shade, a batch of 64 shadow rays to trace, a batch of 64 nodes whose shadow answers are all in
+// to light -- from device-side queues, and produce the items that depend on theirs.  Nothing waits for a bounce to
+// finish: a wavefront that runs out of one kind of work takes another.
+struct StreamCtl {
+    // every hot word on a 64-byte line of its own
+    int node_tail, _p0[15];         // next free node slot; starts at n_primary (a multiple of 64)
+    int nodes_done, _p1[15];        // nodes (in whole batches) whose trace + shading is complete
+    int finish_done, _p2[15];       // nodes (in whole batches) whose lighting is complete
+    int sec_head, _p3[15], sec_tail, _p4[15];   // ring of ready batches of secondary nodes
+    int sh_head, _p5[15], sh_tail, _p6[15];     // ring of ready batches of shadow rays
+    int fin_head, _p7[15], fin_tail, _p8[15];   // ring of node batches ready for lighting
+    int prim_head[8 * 16];          // sharded heads of the primaries' batches (batch b belongs to shard b % 8)
+    int seg_tail[64 * 16];          // next free slot of every light's shadow segment (one line each)
+    int abort, _p9[15];             // != 0: every wavefront leaves (1 pool overflow, 2 timeout)
+    int overflow;                   // 1 node pool, 2 shadow segment
+    int n_children, n_shadow, max_level;        // statistics
+    int timeout_where, _p10[11];
+};
+#define NDT_PRIM_SHARDS 8
+struct StreamArgs {
+    StreamCtl *ctl;
+    int *node_fill;         // [cap / 64]      slots of a node batch that have been written
+    int *sh_pending;        // [cap / 64]      shadow rays of a node batch that are not answered yet
+    int *sh_fill;           // [n_seg][seg_cap / 64]
+    int *sec_ring, *sh_ring, *fin_ring;     // entries: id + 1, 0 = not written yet
+    int *parent, *pend;     // [cap]  the node a node reports to; what a node still waits for (own lighting + children)
+    int *sowner;            // [n_seg * seg_cap]  the node a shadow ray belongs to, -1 = padding slot
+    int n_seg;
+    int seg_cap;            // slots per light segment (multiple of 64)
+    int n_primary;          // multiple of 64
+};
+
 // One table per compiled dimension.
 struct NdtKernelTable {
     int dims;
@@ -132,6 +167,9 @@ struct NdtKernelTable {
                        long long upper_emit);
     void (*hitpoints)(hipStream_t, const double *blob, SceneDesc, const double *o, const double *v, long long stride,
                       const int *prim, double *hit, double *nrm, long long count);
+    // the whole ray tree of a frame in one persistent launch (ndt_stream.hpp); primaries already in the pool
+    void (*frame_stream)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, StreamArgs, int tier, int mask_words,
+                         hipEvent_t ev_start, hipEvent_t ev_stop);
 };
 
 extern "C" const NdtKernelTable *ndt_kernel_table_3();

@@ -1,0 +1,756 @@
+// ndt_stream.hpp -- the streaming frame kernel: the whole ray tree of a frame in ONE persistent launch.
+// Included by ndt_kernels.hip inside the per-dimension namespace (it uses N, the wavefront helpers, light_setup,
+// isect and trace_kd of that translation unit).
+//
+// The bounce-synchronous pipeline (k_trace / k_shade_* per bounce) pays, per bounce, the tail of a trace launch (the
+// chip idles while the last batches finish), the fixed latency of the shade launches and the launch boundaries; five
+// bounces of that were two thirds of a millisecond of a 1.6 ms frame.  Here nothing waits for a bounce: wavefronts are
+// persistent and pull typed work items from device-side queues,
+//
+//   NODE batch    64 consecutive nodes of the pool: trace_kd (closest hit), then in the SAME wavefront everything
+//                 get_ray_color / apply_lights do before their shadow queries (ndt.c:329-430, 71-259): hit point,
+//                 background, reflection / refraction children, one shadow ray per light that passes the same-side
+//                 and cone tests.  Children are appended to the node pool, shadow rays to their light's segment.
+//   SHADOW batch  64 consecutive shadow rays of one light's segment: trace_kd with the ray's dist_limit.
+//   LIGHT batch   a node batch whose shadow rays have all been answered: the second half of apply_lights
+//                 (ndt.c:217-310), then the node's colour travels up the ray tree (below).
+//
+// and produce the items that depend on theirs:
+//   * a pool batch (nodes or shadow rays) becomes a work item when all 64 of its slots have been written: every
+//     writer adds the number of slots it wrote to the batch's fill counter, the one that completes it pushes the
+//     batch onto the ready ring.  A wavefront that finds nothing to do CLOSES the partial batch at the end of a pool by
+//     reserving the rest of it as padding slots -- so nothing ever waits for a batch to fill up;
+//   * a node batch counts its unanswered shadow rays; the wavefront whose answers bring the count to zero pushes it
+//     onto the lighting ring;
+//   * the ray tree is resolved bottom-up as it completes (get_ray_color's blend, ndt.c:402-429): every node counts
+//     what it still waits for (its own lighting + its children); whoever brings that to zero blends the node and
+//     reports to its parent.  Same operands, same order of operations as the recursion: the image does not depend on
+//     which wavefront did what when.
+//
+// Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): the XCDs' L2s are not coherent and a CU's L1 is
+// never refreshed, so every word that is handed from one wavefront to another INSIDE this launch is written with an
+// agent-scope (sc1, write-through) store and read with an agent-scope (sc1) load; a producer drains its stores
+// (s_waitcnt vmcnt(0)) before the atomic that publishes them; consumers reach the data only through an index that
+// atomic (or a value derived from it) handed them.  Plain stores are used only for what later KERNELS read (the
+// resolved colours of the primaries, depth maps).
+
+// ------------------------------------------------------------------ coherent loads / stores, drained publishes
+
+NDT_DEV double cld(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+NDT_DEV void cst(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+NDT_DEV int cldi(const int *p) { return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+NDT_DEV void csti(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+NDT_DEV unsigned long long cldu(const unsigned long long *p)
+{
+    return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+NDT_DEV void cstu(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int K> NDT_DEV void cload_soa(const double *base, long long g, double (&r)[K])
+{
+    const double *t = base + (g >> 6) * (long long)(K * 64) + (g & 63);
+#pragma unroll
+    for (int c = 0; c < K; ++c) r[c] = cld(t + c * 64);
+}
+template <int K> NDT_DEV void cstore_soa(double *base, long long g, const double (&r)[K])
+{
+    double *t = base + (g >> 6) * (long long)(K * 64) + (g & 63);
+#pragma unroll
+    for (int c = 0; c < K; ++c) cst(t + c * 64, r[c]);
+}
+// every store (and returning atomic) this wavefront has issued has been performed
+NDT_DEV void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+NDT_DEV int wave_sum(int x)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// ------------------------------------------------------------------ rings
+
+// Several lanes may push at once (each gets a slot of its own).  The slot is reserved first and written second: a
+// consumer that wins slot h waits for its entry to become non-zero.
+NDT_DEV void ring_push(int *tail, int *ring, int id)
+{
+    const int slot = atomicAdd(tail, 1);
+    csti(ring + slot, id + 1);
+}
+
+// One item for the wavefront (every lane calls; lane 0 works): false when the ring is empty right now.
+NDT_DEV bool ring_pop(int *head, const int *tail, const int *ring, int &id, StreamCtl *ctl)
+{
+    int got = -1;
+    if (__lane_id() == 0) {
+        int h = cldi(head);
+        while (h < cldi(tail)) {
+            const int old = atomicCAS(head, h, h + 1);
+            if (old == h) {
+                int e = cldi(ring + h);
+                for (unsigned spin = 0; e == 0 && spin < (1u << 20); ++spin) {
+                    __builtin_amdgcn_s_sleep(2);
+                    e = cldi(ring + h);
+                }
+                if (e == 0) {           // the producer never wrote its slot: something is badly wrong; everyone out
+                    atomicMax(&ctl->abort, 2);
+                    ctl->timeout_where = 1;
+                }
+                got = e - 1;
+                break;
+            }
+            h = old;
+        }
+    }
+    id = __shfl(got, 0, 64);
+    return id >= 0;
+}
+
+// ------------------------------------------------------------------ the ray tree, bottom-up
+
+// get_ray_color's blend of a node's own colour with what its children returned (ndt.c:402-429): resolve_node of
+// ndt_frame.hip with coherent accesses.  `mat` is the global blob (materials are not staged in LDS).
+NDT_DEV void stream_resolve(const double *mat, const SceneDesc &sd, const Workspace &ws, int specular, long long g)
+{
+    const int obj = cldi(ws.hit_obj + g);
+    const int mw = sd.off_mat + 8 * obj;
+    const double hitr[3] = { mat[mw + 3], mat[mw + 4], mat[mw + 5] };
+    double c[3] = { cld(ws.clr + 0 * ws.cap + g), cld(ws.clr + 1 * ws.cap + g), cld(ws.clr + 2 * ws.cap + g) };
+    int cnt = cldi(ws.count + g);
+    const int refl = cldi(ws.child_refl + g);
+    if (refl != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refl >= 0) {
+            ref[0] = cld(ws.clr + 0 * ws.cap + refl); ref[1] = cld(ws.clr + 1 * ws.cap + refl); ref[2] = cld(ws.clr + 2 * ws.cap + refl);
+            cnt += cldi(ws.count + refl);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (specular) c[k] = (1 - hitr[k]) * (c[k]) + (hitr[k]) * ref[k];     // ndt.c:405-407
+            else c[k] += hitr[k] * ref[k];                                         // ndt.c:411-413
+        }
+    }
+    const int refr = cldi(ws.child_refr + g);
+    if (refr != -1) {
+        double ref[3] = { 0.0, 0.0, 0.0 };
+        if (refr >= 0) {
+            ref[0] = cld(ws.clr + 0 * ws.cap + refr); ref[1] = cld(ws.clr + 1 * ws.cap + refr); ref[2] = cld(ws.clr + 2 * ws.cap + refr);
+            cnt += cldi(ws.count + refr);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] += (1.0 - hitr[k]) * ref[k];              // ndt.c:426-428
+    }
+    cst(ws.clr + 0 * ws.cap + g, c[0]);
+    cst(ws.clr + 1 * ws.cap + g, c[1]);
+    cst(ws.clr + 2 * ws.cap + g, c[2]);
+    csti(ws.count + g, cnt);
+}
+
+// Lanes with `active` report to node `cur` that one of the things it waits for is done (its own lighting, or a child
+// whose colour is final).  The lane that brings the count to zero blends the node and reports to ITS parent, and so on
+// up to the primary.  The caller has drained the stores that made its contribution final.  (Every lane calls.)
+NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace &ws, const StreamArgs &sa, int specular, int cur,
+                         bool active)
+{
+    while (__ballot(active) != 0ull) {
+        if (active) {
+            const int old = atomicSub(sa.pend + cur, 1);
+            if (old != 1) {
+                active = false;
+            } else {
+                stream_resolve(mat, sd, ws, specular, cur);
+                if (cur < sa.n_primary) {
+                    active = false;                 // a primary: k_finish_pixels takes it from here
+                } else {
+                    cur = cldi(sa.parent + cur);
+                }
+            }
+        }
+        drain();        // the blended colours are out before the next level hears of them
+    }
+}
+
+// ------------------------------------------------------------------ lighting of one node batch
+
+// Second half of apply_lights (ndt.c:217-310) for the 64 nodes of batch nb: shade_finish_node with coherent accesses,
+// then the nodes' colours start their way up the tree.  Every lane of the wavefront calls.
+NDT_DEV void stream_light_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
+                                const StreamArgs &sa, int nb)
+{
+    const long long g = (long long)nb * 64 + __lane_id();
+    int obj = -1;
+    if (cldi(ws.depth_left + g) > 0) obj = cldi(ws.hit_obj + g);
+    const bool shaded = obj >= 0;
+    if (shaded) {
+        double src[N], look[N], nrm[N], hit[N];
+        cload_soa<N>(ws.ray_o, g, src);
+        cload_soa<N>(ws.ray_v, g, look);
+        cload_soa<N>(ws.hit_p, g, hit);
+        cload_soa<N>(ws.hit_n, g, nrm);
+        const int mw = sd.off_mat + 8 * obj;
+        const double hit_r = mat[mw], hit_g = mat[mw + 1], hit_b = mat[mw + 2];
+        const double refl_r = mat[mw + 3], refl_g = mat[mw + 4], refl_b = mat[mw + 5];
+        const bool transparent = mat[mw + 7] != 0.0;
+        double hitr_r = 0.0, hitr_g = 0.0, hitr_b = 0.0;
+        if (rg.specular) {
+            hitr_r = refl_r; hitr_g = refl_g; hitr_b = refl_b;
+        }
+        // apply_lights, ndt.c:88-92: scn->ambient first
+        double cr = hit_r * mat[sd.off_cam + 4 * N + 1];
+        double cg = hit_g * mat[sd.off_cam + 4 * N + 2];
+        double cb = hit_b * mat[sd.off_cam + 4 * N + 3];
+        const unsigned long long fire = cldu(ws.sh_mask + g);
+        const unsigned long long key = rg.sample_keys ? cldu(ws.rng_key + g) : 0ull;
+        int n_shadow = 0;
+        int seg = -1;
+        for (int li = 0; li < sd.n_lights; ++li) {
+            const int w = light_word(sd, li);
+            const int ltype = blob_int(mat, w, 0);
+            const double lr_ = mat[w + 1], lg_ = mat[w + 2], lb_ = mat[w + 3];
+            if (ltype == NDT_LIGHT_AMBIENT_) {              // ndt.c:106-111
+                cr += hit_r * lr_;
+                cg += hit_g * lg_;
+                cb += hit_b * lb_;
+                continue;
+            }
+            ++seg;
+            if (!((fire >> li) & 1ull)) continue;
+            const long long slot = (long long)seg * sa.seg_cap + cldi(ws.sh_idx + (long long)seg * ws.cap + g);
+            int type;
+            double lgt_pos[N], rev_light[N], light_vec[N], so[N], light_hit_normal[N];
+            ShadowSetup ss;
+            light_setup(mat, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, key);
+            const int sobj = cldi(ws.sobj + slot);
+            const int sprim = cldi(ws.sprim + slot);
+            ++n_shadow;
+            if (type == NDT_LIGHT_DIRECTIONAL_) {
+                if (sobj >= 0) continue;                    // anything at all shadows it, ndt.c:246
+                v_copy<N>(light_hit_normal, nrm);           // ndt.c:252-254
+            } else {
+                if (sobj != obj) continue;                  // ndt.c:217
+                double light_hit[N];
+                isect<N, true>(blob, sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                const double dist = v_dist<N>(hit, light_hit);
+                if (dist > NDT_EPS) continue;               // ndt.c:225
+            }
+            double angle = v_angle<N>(nrm, light_vec);      // ndt.c:263
+            if (angle > NDT_PI / 2.0) angle = NDT_PI - angle;
+            const double light_scale = cos(angle) / ss.ldist2;
+            if (!transparent) {
+                cr += hit_r * lr_ * light_scale;
+                cg += hit_g * lg_ * light_scale;
+                cb += hit_b * lb_ * light_scale;
+            }
+            if (rg.specular) {                              // ndt.c:276-310
+                double light_ref[N], rev_look[N];
+                v_reflect<N>(light_vec, light_hit_normal, light_ref, 0.5);
+                v_unitize<N>(light_ref);
+                v_scale<N>(look, -1, rev_look);
+                v_unitize<N>(rev_look);
+                double rv = v_dot<N>(light_ref, rev_look);
+                rv = (0 > rv) ? 0 : rv;                     // MAX(0,rv), image.h:31
+                const double rvn = pow(rv, 50.0);
+                const double gb = (lg_ > lb_) ? lg_ : lb_;
+                const double max_light = (lr_ > gb) ? lr_ : gb;
+                cr += hitr_r * lr_ / max_light * rvn;
+                cg += hitr_g * lg_ / max_light * rvn;
+                cb += hitr_b * lb_ / max_light * rvn;
+            }
+        }
+        cst(ws.clr + 0 * ws.cap + g, cr);
+        cst(ws.clr + 1 * ws.cap + g, cg);
+        cst(ws.clr + 2 * ws.cap + g, cb);
+        csti(ws.count + g, 1 + n_shadow);
+    }
+    drain();
+    complete_up(mat, sd, ws, sa, rg.specular, (int)g, shaded);
+    if (__lane_id() == 0) atomicAdd(&sa.ctl->finish_done, 64);
+}
+
+// ------------------------------------------------------------------ shading of one node batch (after its trace_kd)
+
+// What get_ray_color and apply_lights do between the closest-hit query and the shadow queries, for the 64 nodes of
+// batch nb, by the wavefront that has just traced them (src / look / obj / prim are still in its registers): hit point
+// and normal, background colour, children, shadow rays -- shade_emit_node with per-wavefront reservations (the
+// wavefronts of a persistent launch are not in step, so there is no workgroup to share a reservation with; they also
+// do not all arrive at the counters at once).  Every lane of the wavefront calls.
+NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
+                                const StreamArgs &sa, int nb, bool valid, int depth_left, const double (&src)[N],
+                                const double (&look)[N], int obj, int prim)
+{
+    StreamCtl *ctl = sa.ctl;
+    const int lane = __lane_id();
+    const long long g = (long long)nb * 64 + lane;
+    bool shaded = false;
+    double hit[N], nrm[N];
+    if (valid) {
+        if (obj >= 0) {
+            // the hit point and normal trace_kd would have returned: re-run the one primitive that won the traversal
+            isect<N, true>(blob, sd, prim, src, look, hit, nrm);
+            const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
+            shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
+            if (rg.want_depth && g < sa.n_primary) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;     // ndt.c:366-370
+        } else if (rg.want_depth && g < sa.n_primary) {
+            ws.depth[g] = 0.0;                                              // ndt.c:372-373
+        }
+        if (shaded) {
+            cstore_soa<N>(ws.hit_p, g, hit);
+            cstore_soa<N>(ws.hit_n, g, nrm);
+            csti(ws.hit_obj + g, obj);
+            csti(ws.hit_prim + g, prim);
+        } else {
+            // background (ndt.c:436-442); alpha is applied per pixel at the end.  Final at once.
+            csti(ws.hit_obj + g, -1);
+            cst(ws.clr + 0 * ws.cap + g, mat[sd.off_cam + 4 * N + 4]);
+            cst(ws.clr + 1 * ws.cap + g, mat[sd.off_cam + 4 * N + 5]);
+            cst(ws.clr + 2 * ws.cap + g, mat[sd.off_cam + 4 * N + 6]);
+            csti(ws.count + g, 1);
+        }
+    }
+    const bool live = __ballot(shaded) != 0ull;
+    int n_sh_batch = 0;             // shadow rays of the whole batch
+    if (live) {
+        // ---- which lights fire (ndt.c:113-208): one shadow ray per light that passes the same-side / cone tests
+        unsigned long long fire = 0ull;
+        const unsigned long long node_key = (rg.sample_keys && valid) ? cldu(ws.rng_key + g) : 0ull;       // stochastic renders only
+        if (shaded) {
+            for (int li = 0; li < sd.n_lights; ++li) {
+                int type;
+                double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+                ShadowSetup ss;
+                if (light_setup(mat, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, node_key)) fire |= 1ull << li;
+            }
+        }
+        // lane s learns how many lanes fire segment s's light
+        int my_total = 0, seg = 0;
+        for (int li = 0; li < sd.n_lights; ++li) {
+            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;      // wave-uniform
+            const unsigned long long vote = __ballot((fire >> li) & 1ull);
+            if (lane == seg) my_total = __popcll(vote);
+            ++seg;
+        }
+        if (shaded) cstu(ws.sh_mask + g, fire);
+        // ---- get_ray_color, ndt.c:381-430: reflection / refraction children
+        bool want_refl = false, want_refr = false;
+        double refl_ray[N], refr_ray[N];
+        double refl_frac = 0, refr_frac = 0;
+        int depth_next = 0;
+        int c_refl = -1, c_refr = -1;
+        if (shaded) {
+            const int mw = sd.off_mat + 8 * obj;
+            const double refl_r = mat[mw + 3], refl_g = mat[mw + 4], refl_b = mat[mw + 5];
+            const bool transparent = mat[mw + 7] != 0.0;
+            const double frac = cld(ws.frac + g);
+            depth_next = depth_left - 1;
+            const double gb2 = (refl_g > refl_b) ? refl_g : refl_b;
+            const double contrib = (refl_r > gb2) ? refl_r : gb2;
+            if (contrib > 0 && (refl_r != 0.0 || refl_g != 0.0 || refl_b != 0.0)) {
+                refl_frac = contrib * frac;
+                // child cut-offs (ndt.c:336-341) return black without tracing
+                if (refl_frac < (1.0 / 512.0) || depth_next <= 0) {
+                    c_refl = -2;
+                } else {
+                    v_reflect<N>(look, nrm, refl_ray, 1.0);
+                    v_unitize<N>(refl_ray);
+                    want_refl = true;
+                }
+            }
+            if (transparent) {
+                refr_frac = (1 - contrib) * frac;
+                if (refr_frac < (1.0 / 512.0) || depth_next <= 0) {
+                    c_refr = -2;
+                } else {
+                    double nrm_u[N];                                    // vectNd_refract unitizes the normal it is given (vectNd.c:155);
+                    v_copy<N>(nrm_u, nrm);                              // the shadow rays below still need the original
+                    v_refract<N>(look, nrm_u, refr_ray, mat[mw + 6]);
+                    v_unitize<N>(refr_ray);
+                    want_refr = true;
+                }
+            }
+        }
+        // ---- reservations: the children at the node tail, the shadow rays in their lights' segments
+        const unsigned long long v_refl = __ballot(want_refl), v_refr = __ballot(want_refr);
+        const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
+        int base = 0;
+        if (total > 0) {
+            if (lane == 0) base = atomicAdd(&ctl->node_tail, total);
+            if (lane == 1) atomicAdd(&ctl->n_children, total);
+            base = __shfl(base, 0, 64);
+            if ((long long)base + total > ws.cap) {
+                // node pool overflow: flag it (the host renders the frame again with a larger pool); everyone leaves
+                if (lane == 0) {
+                    atomicOr(&ctl->overflow, 1);
+                    atomicMax(&ctl->abort, 1);
+                }
+                return;
+            }
+        }
+        int my_base = 0;
+        n_sh_batch = wave_sum(my_total);
+        if (my_total > 0) {
+            my_base = atomicAdd(&ctl->seg_tail[lane * 16], my_total);
+            if ((long long)my_base + my_total > sa.seg_cap) {
+                atomicOr(&ctl->overflow, 2);
+                atomicMax(&ctl->abort, 1);
+            }
+        }
+        if (lane == 63 && n_sh_batch > 0) atomicAdd(&ctl->n_shadow, n_sh_batch);
+        if (__ballot(my_total > 0 && (long long)my_base + my_total > sa.seg_cap) != 0ull) return;
+        // ---- the children
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (want_refl) {
+            const long long c = (long long)base + __popcll(v_refl & below);
+            cstore_soa<N>(ws.ray_o, c, hit);
+            cstore_soa<N>(ws.ray_v, c, refl_ray);
+            cst(ws.frac + c, refl_frac);
+            csti(ws.depth_left + c, depth_next);
+            csti(sa.parent + c, (int)g);
+            if (rg.sample_keys) cstu(ws.rng_key + c, ndt_rng_mix(node_key ^ 0x1ull));
+            c_refl = (int)c;
+        }
+        if (want_refr) {
+            const long long c = (long long)base + n_refl + __popcll(v_refr & below);
+            cstore_soa<N>(ws.ray_o, c, hit);
+            cstore_soa<N>(ws.ray_v, c, refr_ray);
+            cst(ws.frac + c, refr_frac);
+            csti(ws.depth_left + c, depth_next);
+            csti(sa.parent + c, (int)g);
+            if (rg.sample_keys) cstu(ws.rng_key + c, ndt_rng_mix(node_key ^ 0x2ull));
+            c_refr = (int)c;
+        }
+        if (shaded) {
+            csti(ws.child_refl + g, c_refl);
+            csti(ws.child_refr + g, c_refr);
+            // what the node waits for before its colour is final: its own lighting and its children
+            csti(sa.pend + g, 1 + (c_refl >= 0 ? 1 : 0) + (c_refr >= 0 ? 1 : 0));
+        }
+        if (total > 0) {
+            // statistics: the deepest bounce that has nodes
+            int lvl = (want_refl || want_refr) ? rg.max_depth - depth_next : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) lvl = max(lvl, __shfl_xor(lvl, d, 64));
+            if (lane == 2) atomicMax(&ctl->max_level, lvl);
+        }
+        // ---- the shadow rays, into their segments
+        seg = 0;
+        for (int li = 0; li < sd.n_lights; ++li) {
+            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
+            const bool fires = (fire >> li) & 1ull;
+            const unsigned long long vote = __ballot(fires);
+            const int sbase = __shfl(my_base, seg, 64);
+            if (fires) {
+                int type;
+                double lgt_pos[N], rev_light[N], light_vec[N], so[N];
+                ShadowSetup ss;
+                light_setup(mat, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, node_key);
+                const int idx = sbase + __popcll(vote & below);
+                const long long slot = (long long)seg * sa.seg_cap + idx;
+                csti(ws.sh_idx + (long long)seg * ws.cap + g, idx);
+                cstore_soa<N>(ws.so, slot, so);
+                // point/spot: from the light along light_vec (ndt.c:211); directional: from the nudged hit point along
+                // rev_light (ndt.c:238) -- one store of a selected VALUE (two stores from different arrays end in scratch)
+                double dir[N];
+#pragma unroll
+                for (int c = 0; c < N; ++c) dir[c] = (type == NDT_LIGHT_DIRECTIONAL_) ? rev_light[c] : light_vec[c];
+                cstore_soa<N>(ws.sv, slot, dir);
+                cst(ws.slim + slot, ss.dist_limit);
+                csti(sa.sowner + slot, (int)g);
+            }
+            ++seg;
+        }
+        // the batch's unanswered shadow rays: counted BEFORE any of them can be answered
+        if (n_sh_batch > 0 && lane == 0) atomicAdd(sa.sh_pending + nb, n_sh_batch);
+        drain();
+        // ---- publish: every pool batch we wrote into learns how many of its slots are now written
+        if (total > 0 && lane < 3) {
+            const int kb = (base >> 6) + lane;
+            if (kb <= ((base + total - 1) >> 6)) {
+                const int lo = base > kb * 64 ? base : kb * 64, hi = base + total < (kb + 1) * 64 ? base + total : (kb + 1) * 64;
+                const int old = atomicAdd(sa.node_fill + kb, hi - lo);
+                if (old + (hi - lo) == 64) ring_push(&ctl->sec_tail, sa.sec_ring, kb);
+            }
+        }
+        if (my_total > 0) {
+            const int bps = sa.seg_cap >> 6;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = (my_base >> 6) + j;
+                if (k <= ((my_base + my_total - 1) >> 6)) {
+                    const int lo = my_base > k * 64 ? my_base : k * 64, hi = my_base + my_total < (k + 1) * 64 ? my_base + my_total : (k + 1) * 64;
+                    const int old = atomicAdd(sa.sh_fill + lane * bps + k, hi - lo);
+                    if (old + (hi - lo) == 64) ring_push(&ctl->sh_tail, sa.sh_ring, lane * bps + k);
+                }
+            }
+        }
+    } else {
+        drain();
+    }
+    // ---- nodes that are final already (background): their parents hear of it
+    {
+        const bool bg_child = valid && !shaded && g >= sa.n_primary;
+        int par = 0;
+        if (bg_child) par = cldi(sa.parent + g);
+        complete_up(mat, sd, ws, sa, rg.specular, par, bg_child);
+    }
+    // ---- the batch's lighting: later (when its shadow rays are answered), now (it has none), or never (nothing was hit)
+    if (!live) {
+        if (lane == 0) atomicAdd(&ctl->finish_done, 64);
+    } else if (n_sh_batch == 0) {
+        stream_light_batch(blob, mat, sd, ws, rg, sa, nb);
+    }
+    if (lane == 0) atomicAdd(&ctl->nodes_done, 64);
+}
+
+// ------------------------------------------------------------------ idle wavefronts close the partial batches
+
+// Reserve the rest of the batch at the end of the node pool / of every shadow segment as padding slots, so that
+// the batch becomes a work item.  Only called by a wavefront that found no work: while there is other work, batches
+// fill up by themselves.  Every lane calls.
+NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
+{
+    StreamCtl *ctl = sa.ctl;
+    const int lane = __lane_id();
+    // node pool
+    {
+        int t = 0, won = 0;
+        if (lane == 0) {
+            t = cldi(&ctl->node_tail);
+            if ((t & 63) != 0 && t < ws.cap) won = atomicCAS(&ctl->node_tail, t, (t + 63) & ~63) == t;
+        }
+        t = __shfl(t, 0, 64);
+        won = __shfl(won, 0, 64);
+        if (won) {
+            const int pad = 64 - (t & 63);
+            if (lane < pad) {
+                csti(ws.depth_left + t + lane, 0);      // never traced, never shaded
+                csti(ws.hit_obj + t + lane, -1);
+            }
+            drain();
+            if (lane == 0) {
+                const int old = atomicAdd(sa.node_fill + (t >> 6), pad);
+                if (old + pad == 64) ring_push(&ctl->sec_tail, sa.sec_ring, t >> 6);
+            }
+        }
+    }
+    // shadow segments: lane s closes segment s
+    {
+        int t = 0, won = 0;
+        if (lane < sa.n_seg) {
+            t = cldi(&ctl->seg_tail[lane * 16]);
+            if ((t & 63) != 0 && t < sa.seg_cap) won = atomicCAS(&ctl->seg_tail[lane * 16], t, (t + 63) & ~63) == t;
+        }
+        unsigned long long winners = __ballot(won != 0);
+        while (winners) {
+            const int s = __ffsll((long long)winners) - 1;
+            winners &= winners - 1;
+            const int ts = __shfl(t, s, 64);
+            const int pad = 64 - (ts & 63);
+            if (lane < pad) csti(sa.sowner + (long long)s * sa.seg_cap + ts + lane, -1);
+            drain();
+            if (lane == 0) {
+                const int bps = sa.seg_cap >> 6;
+                const int old = atomicAdd(sa.sh_fill + s * bps + (ts >> 6), pad);
+                if (old + pad == 64) ring_push(&ctl->sh_tail, sa.sh_ring, s * bps + (ts >> 6));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+
+template <int MW, bool LDS, bool LSTACK = false>
+__global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const double *gblob, SceneDesc sd, Workspace ws, RenderGeom rg,
+                                                                      StreamArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_blob[];
+    const double *blob = gblob;
+    if (LDS) {
+        const int pairs = sd.trace_words >> 1;
+        const ndt_v2d *src2 = reinterpret_cast<const ndt_v2d *>(gblob);
+        ndt_v2d *dst2 = reinterpret_cast<ndt_v2d *>(lds_blob);
+        int i = threadIdx.x;
+        for (; i + 3 * (int)blockDim.x < pairs; i += 4 * blockDim.x) {
+            const ndt_v2d a = src2[i], b = src2[i + blockDim.x], c = src2[i + 2 * blockDim.x], d = src2[i + 3 * blockDim.x];
+            dst2[i] = a; dst2[i + blockDim.x] = b; dst2[i + 2 * blockDim.x] = c; dst2[i + 3 * blockDim.x] = d;
+        }
+        for (; i < pairs; i += blockDim.x) dst2[i] = src2[i];
+        if ((sd.trace_words & 1) && threadIdx.x == 0) lds_blob[sd.trace_words - 1] = gblob[sd.trace_words - 1];
+        __syncthreads();
+        blob = lds_blob;
+    }
+    KdStackLds kstack{};
+    if (LSTACK) {
+        double *base = lds_blob + ((sd.trace_words + 1) & ~1);
+        const int depth = sd.kd_depth + 1;
+        kstack.stride = blockDim.x;
+        kstack.tu = base + threadIdx.x;
+        kstack.node = (int *)(base + (size_t)depth * blockDim.x) + threadIdx.x;
+    }
+    VisitMask<MW> mask;
+    mask.ext = nullptr;
+    mask.ext_stride = 0;
+    if (MW == 0) {
+        const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        mask.ext = ws.mask_slab + lane_slot;
+        mask.ext_stride = (int)ws.mask_slab_lanes;
+    }
+    StreamCtl *ctl = sa.ctl;
+    const int lane = __lane_id();
+    const int n_prim_batches = sa.n_primary >> 6;
+    int shard = blockIdx.x % NDT_PRIM_SHARDS;
+    unsigned shards_alive = (1u << NDT_PRIM_SHARDS) - 1u;
+    const unsigned long long t_begin = wall_clock64();          // 100 MHz
+    int idle_rounds = 0;
+    while (true) {
+        if (cldi(&ctl->abort) != 0) break;
+        // ---- take a work item: deeper rays first (they start the chains everything else waits for), lighting last
+        int kind = 0, id = -1;          // 1 node batch, 2 shadow batch, 3 lighting batch
+        if (ring_pop(&ctl->sec_head, &ctl->sec_tail, sa.sec_ring, id, ctl)) {
+            kind = 1;
+        } else {
+            while (shards_alive != 0u && kind == 0) {
+                if ((shards_alive >> shard) & 1u) {
+                    int k = 0;
+                    if (lane == 0) k = atomicAdd(&ctl->prim_head[shard * 16], 1);
+                    k = __shfl(k, 0, 64);
+                    const int b = k * NDT_PRIM_SHARDS + shard;
+                    if (b < n_prim_batches) {
+                        kind = 1;
+                        id = b;
+                    } else {
+                        shards_alive &= ~(1u << shard);
+                    }
+                }
+                if (kind == 0) shard = (shard + 1) % NDT_PRIM_SHARDS;
+            }
+            if (kind == 0) {
+                if (ring_pop(&ctl->sh_head, &ctl->sh_tail, sa.sh_ring, id, ctl)) kind = 2;
+                else if (ring_pop(&ctl->fin_head, &ctl->fin_tail, sa.fin_ring, id, ctl)) kind = 3;
+            }
+        }
+        if (kind == 1 || kind == 2) {
+            idle_rounds = 0;
+            // ---- trace_kd for 64 rays: the nodes of batch `id`, or the shadow rays of batch `id`
+            const bool is_shadow = kind == 2;
+            long long slot;
+            if (is_shadow) {
+                const int bps = sa.seg_cap >> 6;
+                const int s = id / bps, k = id - s * bps;
+                slot = (long long)s * sa.seg_cap + (long long)k * 64 + lane;
+            } else {
+                slot = (long long)id * 64 + lane;
+            }
+            const int tag = is_shadow ? cldi(sa.sowner + slot) : cldi(ws.depth_left + slot);     // owner node / bounces left
+            const bool valid = is_shadow ? tag >= 0 : tag > 0;
+            double o[N], v[N];
+            double lim = -1.0;
+            int obj = -1, prim = -1;
+            if (valid) {
+                cload_soa<N>(is_shadow ? ws.so : ws.ray_o, slot, o);
+                cload_soa<N>(is_shadow ? ws.sv : ws.ray_v, slot, v);
+                if (is_shadow) lim = cld(ws.slim + slot);
+                trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+            } else {
+#pragma unroll
+                for (int c = 0; c < N; ++c) { o[c] = 0.0; v[c] = 0.0; }
+            }
+            if (is_shadow) {
+                if (valid) {
+                    csti(ws.sobj + slot, obj);
+                    csti(ws.sprim + slot, prim);
+                }
+                drain();
+                // the rays of one node batch are consecutive in a segment: the first lane of every run reports the whole run
+                const int nb = tag >> 6;
+                const int nb_prev = __shfl_up(nb, 1, 64);
+                const bool valid_prev = __shfl_up((int)valid, 1, 64) != 0;
+                const bool head = valid && (lane == 0 || !valid_prev || nb_prev != nb);
+                const unsigned long long heads = __ballot(head), valids = __ballot(valid);
+                if (head) {
+                    const unsigned long long above = (lane < 63) ? (heads >> (lane + 1)) << (lane + 1) : 0ull;
+                    const int end = above ? __ffsll((long long)above) - 1 : 64;         // the next run's first lane
+                    const unsigned long long span = (end < 64 ? (1ull << end) - 1ull : ~0ull) & ~((1ull << lane) - 1ull);
+                    const int run = __popcll(valids & span);
+                    const int old = atomicSub(sa.sh_pending + nb, run);
+                    if (old == run) ring_push(&ctl->fin_tail, sa.fin_ring, nb);
+                }
+            } else {
+                stream_shade_batch(blob, gblob, sd, ws, rg, sa, id, valid, tag, o, v, obj, prim);
+            }
+        } else if (kind == 3) {
+            idle_rounds = 0;
+            stream_light_batch(blob, gblob, sd, ws, rg, sa, id);
+        } else {
+            // ---- nothing to do right now: is the frame done?  (read in this order: a node batch bumps the tail
+            // before it counts itself done, so done == tail means no node batch is in flight or will ever be)
+            const int done = cldi(&ctl->nodes_done);
+            const int tail = cldi(&ctl->node_tail);
+            const int lit = cldi(&ctl->finish_done);
+            if (done == tail && lit == tail) break;
+            stream_close_partials(ws, sa);
+            ++idle_rounds;
+            if (idle_rounds < 8) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(32);
+            if ((idle_rounds & 63) == 0 && wall_clock64() - t_begin > 400000000ull) {     // 4 s: never on a healthy frame
+                if (lane == 0) {
+                    atomicMax(&ctl->abort, 2);
+                    ctl->timeout_where = 2;
+                }
+                break;
+            }
+        }
+    }
+}
+
+#define NDT_LAUNCH_STREAM(kernel, grid, block, lds)                                                            \
+    do {                                                                                                       \
+        if (ev_start)                                                                                          \
+            hipExtLaunchKernelGGL((kernel), dim3((unsigned)(grid)), dim3(block), (std::uint32_t)(lds), s, ev_start, ev_stop, 0u, blob, sd, ws, rg, sa); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((kernel), dim3((unsigned)(grid)), dim3(block), lds, s, blob, sd, ws, rg, sa);   \
+    } while (0)
+
+// Persistent grid: as many workgroups as are resident (fewer for a frame with little work: a wavefront without work
+// only polls).  Same tiers as launch_trace: scene and traversal stack in LDS with 768-lane workgroups where they fit,
+// the scene in LDS with a scratch stack, or everything in global memory with visit masks in the slab.
+static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, StreamArgs sa, int tier,
+                                int mask_words, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const long long batches = sa.n_primary >> 6;
+    // work items of a frame: a few per primary batch; a grid beyond that cannot help
+    auto grid_for_work = [&](int res, int block) {
+        long long want = (batches * 3 + (block / 64) - 1) / (block / 64) + 1;
+        return (int)(want < res ? want : res);
+    };
+    if (tier == 0) {
+        const size_t lds = (size_t)sd.trace_words * sizeof(double);
+        int lstack_block = NDT_TRACE_MAX_BLOCK;
+        if (batches < 4096) lstack_block = 256;         // a small frame is pure latency: one wavefront per SIMD
+        const size_t lds_stack = ((size_t)((sd.trace_words + 1) & ~1) * 8) + (size_t)lstack_block * (sd.kd_depth + 1) * 12;
+        if (lds_stack <= 160 * 1024 && mask_words <= 1) {
+            const int res = resident_blocks(k_frame_stream<1, true, true>, lstack_block, lds_stack);
+            NDT_LAUNCH_STREAM((k_frame_stream<1, true, true>), grid_for_work(res, lstack_block), lstack_block, lds_stack);
+        } else if (lds_stack <= 160 * 1024) {
+            const int res = resident_blocks(k_frame_stream<NDT_MASK_REG_WORDS, true, true>, lstack_block, lds_stack);
+            NDT_LAUNCH_STREAM((k_frame_stream<NDT_MASK_REG_WORDS, true, true>), grid_for_work(res, lstack_block), lstack_block, lds_stack);
+        } else if (mask_words <= 1) {
+            const int res = resident_blocks(k_frame_stream<1, true>, NDT_TRACE_BLOCK, lds);
+            NDT_LAUNCH_STREAM((k_frame_stream<1, true>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, lds);
+        } else {
+            const int res = resident_blocks(k_frame_stream<NDT_MASK_REG_WORDS, true>, NDT_TRACE_BLOCK, lds);
+            NDT_LAUNCH_STREAM((k_frame_stream<NDT_MASK_REG_WORDS, true>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, lds);
+        }
+    } else {
+        int res = resident_blocks(k_frame_stream<0, false>, NDT_TRACE_BLOCK, 0);
+        const long long max_blocks = ws.mask_slab_lanes / NDT_TRACE_BLOCK;
+        if (res > max_blocks) res = (int)max_blocks;
+        NDT_LAUNCH_STREAM((k_frame_stream<0, false>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, 0);
+    }
+}

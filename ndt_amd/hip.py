@@ -19,8 +19,11 @@ API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
     "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes",
-    "ndt_hip_render_depth_device", "ndt_hip_render_depth",
+    "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
+    "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device",
 ]
+
+IMAGE_F64, IMAGE_RGBA8 = 0, 1      # enum ndt_image_format
 
 
 class NdtHipError(RuntimeError):
@@ -66,6 +69,10 @@ def load_library():
     lib.ndt_hip_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.ndt_hip_hcube_hull_box.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_multi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_device.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -174,6 +181,15 @@ class NdtHip:
         self._check(self.lib.ndt_hip_render_device(self.ctx, C.byref(p), C.c_void_p(d_rgba_ptr), C.byref(st)))
         return st
 
+    def render_rgba8(self, width, height, depth, **kw):
+        """render_image + the reference's save-time quantisation on the device: (rows, width, 4) uint8 host array, stats."""
+        p = self.params(width, height, depth, **kw)
+        rows = shard_rows(height, p.row_begin, p.row_step)
+        out = np.zeros((rows, width, 4), dtype=np.uint8)
+        st = RenderStats()
+        self._check(self.lib.ndt_hip_render_rgba8(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return out, st
+
     def quantize_device(self, d_rgba_ptr, d_rgba8_ptr, n_pixels):
         self._check(self.lib.ndt_hip_quantize_device(self.ctx, C.c_void_p(d_rgba_ptr), C.c_void_p(d_rgba8_ptr),
                                                      int(n_pixels)))
@@ -192,3 +208,21 @@ class NdtHip:
                                                 lim.ctypes.data_as(C.c_void_p), obj.ctypes.data_as(C.c_void_p),
                                                 hit.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p)))
         return obj, hit, nrm
+
+
+def render_multi(contexts, width, height, depth, fmt=IMAGE_F64, d_out_ptr=None, **kw):
+    """ONE frame over several NdtHip contexts (one per GPU, or several on one GPU) from this one thread:
+    ndt_hip_render_multi.  Rows are dealt cyclically like the reference's MPI_MODE_ROW (ndt.c:812-820); every context
+    must hold the same uploaded scene.  Returns (image, stats): float64 (rows, width, 4) or uint8 for IMAGE_RGBA8;
+    with d_out_ptr (memory of contexts[0]'s device) the image stays there and only the stats come back."""
+    first = contexts[0]
+    p = first.params(width, height, depth, **kw)
+    arr = (C.c_void_p * len(contexts))(*[c.ctx for c in contexts])
+    st = RenderStats()
+    if d_out_ptr is not None:
+        first._check(first.lib.ndt_hip_render_multi_device(arr, len(contexts), C.byref(p), int(fmt), C.c_void_p(d_out_ptr), C.byref(st)))
+        return None, st
+    rows = shard_rows(height, p.row_begin, p.row_step)
+    out = np.zeros((rows, width, 4), dtype=np.uint8 if fmt == IMAGE_RGBA8 else np.float64)
+    first._check(first.lib.ndt_hip_render_multi(arr, len(contexts), C.byref(p), int(fmt), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+    return out, st

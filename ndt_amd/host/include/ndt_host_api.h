@@ -398,6 +398,20 @@ int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_d
 int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
                           int specular, int max_optic_depth, double *rgba, double *depth);
 
+/* The same frame as the bytes the reference stores (pixel_d2c on every channel, image.h:36-39; quantised on the GPU):
+ * `rgba8` receives width*height*4 bytes.  What the driver writes PPM / PNG files from. */
+int ndt_render_image_rgba8(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
+                           int specular, int max_optic_depth, unsigned char *rgba8);
+
+/* Which GPUs the calling thread's frames are rendered on (the settings are per thread, like the GPU contexts):
+ *   ndt_render_use_device(d)     one context on device d -- `ndt_hip -j K` gives worker w device w mod device count,
+ *                                the reference's MPI_MODE_FRAME (one frame per rank, ndt.c:1770-1830);
+ *   ndt_render_use_devices(n)    ONE frame over n contexts, context k on device k mod device count, rows dealt
+ *                                cyclically -- the reference's MPI_MODE_ROW (ndt.c:812-820), `ndt_hip -g n`.
+ * Both drop the thread's contexts if the choice changes.  Default: one context on device 0. */
+void ndt_render_use_device(int device);
+void ndt_render_use_devices(int n_contexts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,43 +20,68 @@ static double now_s(void)
     return tv.tv_sec + 1e-6 * tv.tv_usec;
 }
 
-static int write_png(const char *path, const double *rgba, int w, int h);
+static int write_png(const char *path, const unsigned char *rgba8, int w, int h);
 
-static int write_ppm(const char *path, const double *rgba, int w, int h)
+/* both writers take the bytes the reference stores: pixel_d2c of every channel (image.h:36-39, image.c:648-651) */
+static int write_ppm(const char *path, const unsigned char *rgba8, int w, int h)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
     fprintf(f, "P6\n%d %d\n255\n", w, h);
-    for (long i = 0; i < (long)w * h; ++i) {
-        unsigned char px[3];
-        for (int c = 0; c < 3; ++c) {
-            double d = rgba[4 * i + c];
-            double m = (1.0 < d) ? 1.0 : d;                 /* pixel_d2c, image.h:36-39 */
-            m = (0.0 > m) ? 0.0 : m;
-            px[c] = (unsigned char)(sqrt(m) * 255);
-        }
-        fwrite(px, 1, 3, f);
+    unsigned char *row = (unsigned char *)malloc((size_t)w * 3);
+    for (int j = 0; j < h; ++j) {
+        for (int i = 0; i < w; ++i)
+            for (int c = 0; c < 3; ++c) row[3 * i + c] = rgba8[((size_t)j * w + i) * 4 + c];
+        fwrite(row, 1, (size_t)w * 3, f);
     }
+    free(row);
     fclose(f);
     return 0;
+}
+
+/* pixel_d2c on the host: only for images that are in doubles here anyway (--raw, the normalised depth map) */
+static unsigned char *quantise(const double *rgba, long n_values)
+{
+    unsigned char *out = (unsigned char *)malloc((size_t)n_values);
+    for (long i = 0; i < n_values; ++i) {
+        double d = rgba[i];
+        double m = (1.0 < d) ? 1.0 : d;
+        m = (0.0 > m) ? 0.0 : m;
+        out[i] = (unsigned char)(sqrt(m) * 255);
+    }
+    return out;
 }
 
 
 /* ---- one frame: flatten, upload, render, save (what follows scene_setup in the reference's frame loop) */
 static struct {
-    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth, samples, png;
+    int dims, width, height, depth, threads, aa_diff, aa_depth, stereo, specular, want_depth, samples, png, gpus;
     const char *raw_path;
 } job_opts;
 
 static int render_frame(scene *scn, int i)
 {
     const int width = job_opts.width, height = job_opts.height;
-    double *rgba = (double *)malloc((size_t)width * height * 4 * sizeof(double));
+    /* the image in doubles only when something asks for it (--raw, the depth map of -z); otherwise the GPU quantises
+     * and 4 bytes per pixel come back instead of 32 */
+    const int want_f64 = job_opts.raw_path != NULL || job_opts.want_depth;
+    double *rgba = want_f64 ? (double *)malloc((size_t)width * height * 4 * sizeof(double)) : NULL;
     double *depth_map = job_opts.want_depth ? (double *)malloc((size_t)width * height * sizeof(double)) : NULL;
+    unsigned char *rgba8 = NULL;
     double t0 = now_s();
-    if (!ndt_render_image_full(scn, width, height, job_opts.samples, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth,
-                               job_opts.stereo, job_opts.specular, job_opts.depth, rgba, depth_map)) {
+    int ok;
+    if (want_f64) {
+        ok = ndt_render_image_full(scn, width, height, job_opts.samples, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth,
+                                   job_opts.stereo, job_opts.specular, job_opts.depth, rgba, depth_map);
+        if (ok) rgba8 = quantise(rgba, (long)width * height * 4);
+    } else {
+        rgba8 = (unsigned char *)malloc((size_t)width * height * 4);
+        ok = ndt_render_image_rgba8(scn, width, height, job_opts.samples, job_opts.threads, job_opts.aa_diff, job_opts.aa_depth,
+                                    job_opts.stereo, job_opts.specular, job_opts.depth, rgba8);
+    }
+    if (!ok) {
         free(rgba);
+        free(rgba8);
         free(depth_map);
         return 0;
     }
@@ -68,10 +93,10 @@ static int render_frame(scene *scn, int i)
     snprintf(dir, sizeof(dir), "images/%s/%id/%ix%i", scn->name, job_opts.dims, width, height); mkdir(dir, 0700);
     if (job_opts.png) {
         snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.png", dir, scn->name, width, height, i);
-        write_png(path, rgba, width, height);
+        write_png(path, rgba8, width, height);
     } else {
         snprintf(path, sizeof(path), "%s/%s_%ix%i_%04i.ppm", dir, scn->name, width, height, i);
-        write_ppm(path, rgba, width, height);
+        write_ppm(path, rgba8, width, height);
     }
     printf("\tsaved %s\n", path);
     if (depth_map) {
@@ -89,8 +114,10 @@ static int render_frame(scene *scn, int i)
         }
         mkdir("depth", 0700);
         snprintf(path, sizeof(path), "depth/%s_%ix%i_%04i.ppm", scn->name, width, height, i);
-        write_ppm(path, norm, width, height);
+        unsigned char *norm8 = quantise(norm, (long)width * height * 4);
+        write_ppm(path, norm8, width, height);
         printf("\tsaved %s\n", path);
+        free(norm8);
         free(norm);
         if (job_opts.raw_path) {
             char dpath[1100];
@@ -104,6 +131,7 @@ static int render_frame(scene *scn, int i)
         if (f) { fwrite(rgba, sizeof(double), (size_t)width * height * 4, f); fclose(f); }
     }
     free(rgba);
+    free(rgba8);
     free(depth_map);
     return 1;
 }
@@ -136,7 +164,12 @@ static void queue_close(void)
 
 static void *worker_main(void *arg)
 {
-    (void)arg;
+    /* worker w renders its frames on device w mod device count: one frame per GPU, the reference's MPI_MODE_FRAME
+     * (ndt.c:1770-1830); with -g n every frame is spread over n contexts instead */
+    const int w = (int)(long)arg;
+    const int n_dev = ndt_hip_device_count();
+    if (job_opts.gpus > 1) ndt_render_use_devices(job_opts.gpus);
+    else ndt_render_use_device(n_dev > 0 ? w % n_dev : 0);
     for (;;) {
         pthread_mutex_lock(&queue_mu);
         while (queue_n == 0 && !queue_done) pthread_cond_wait(&queue_not_empty, &queue_mu);
@@ -205,7 +238,7 @@ static void png_chunk(FILE *f, const char *type, const unsigned char *data, size
     fwrite(tail, 1, 4, f);
 }
 
-static int write_png(const char *path, const double *rgba, int w, int h)
+static int write_png(const char *path, const unsigned char *rgba8, int w, int h)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
@@ -223,13 +256,7 @@ static int write_png(const char *path, const double *rgba, int w, int h)
     for (int j = 0; j < h; ++j) {
         unsigned char *q = raw + (size_t)j * row;
         *q++ = 0;
-        for (int i = 0; i < w; ++i)
-            for (int c = 0; c < 4; ++c) {
-                double d = rgba[((size_t)j * w + i) * 4 + c];
-                double m = (1.0 < d) ? 1.0 : d;                 /* pixel_d2c, image.h:36-39 */
-                m = (0.0 > m) ? 0.0 : m;
-                *q++ = (unsigned char)(sqrt(m) * 255);
-            }
+        memcpy(q, rgba8 + (size_t)j * w * 4, (size_t)w * 4);
     }
     /* zlib: header, stored blocks of at most 65535 bytes, adler32 */
     const size_t n_blocks = (raw_len + 65534) / 65535;
@@ -265,7 +292,8 @@ int main(int argc, char **argv)
     int dims = 3, width = 1920, height = 1080, first = 0, last = -1, frames = 300, frames_given = 0;
     int depth = 128, threads = 1;
     int aa_diff = 20, aa_depth = -1;        /* -a: recursive anti-aliasing off unless given (ndt.c:1411-1412, 1453) */
-    int jobs = 1;           /* -j: frames in flight */
+    int jobs = 1;           /* -j: frames in flight, worker w on GPU w mod device count (MPI_MODE_FRAME, ndt.c:1770-1830) */
+    int gpus = 1;           /* -g: contexts ONE frame is spread over, context k on GPU k mod device count (MPI_MODE_ROW, ndt.c:812-820) */
     int png = 0;            /* --png: 8-bit RGBA PNG like the reference's default IMAGE_FORMAT (image.h:56-64) instead of PPM */
     int samples = 1;        /* -n (ndt.c:1574-1577) */
     int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
@@ -274,7 +302,7 @@ int main(int argc, char **argv)
                                         { "raw", required_argument, NULL, 1001 }, { "png", no_argument, NULL, 1002 },
                                         { NULL, 0, NULL, 0 } };
     int ch;
-    while ((ch = getopt_long(argc, argv, "a:d:r:f:j:l:m:3:n:ps:t:u:o:zh", longopts, NULL)) != -1) {
+    while ((ch = getopt_long(argc, argv, "a:d:g:r:f:j:l:m:3:n:ps:t:u:o:zh", longopts, NULL)) != -1) {
         int a1, a2, a3, n;
         switch (ch) {
         case 'a':       /* -a diff,depth (ndt.c:1453-1465); defaults 20,4 */
@@ -298,6 +326,7 @@ int main(int argc, char **argv)
             else if (n >= 2) { first = a1; last = a2; }
             else if (n >= 1) { last = a1; }
             break;
+        case 'g': gpus = atoi(optarg); break;
         case 'j': jobs = atoi(optarg); break;
         case 'l': depth = atoi(optarg); break;
         case 'm':
@@ -322,7 +351,7 @@ int main(int argc, char **argv)
         case 1002: png = 1; break;
         default:
             fprintf(stderr, "usage: %s -s scene.so|builtin:yaml [-d dims] [-r WxH|1080p|4k] [-f last|first:last[:total]] [-l depth]\n"
-                            "          [-a diff,depth] [-n samples] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-u config] [--dump-scene file.ndtscene] [--raw file.f64] [--png]\n", argv[0]);
+                            "          [-a diff,depth] [-n samples] [-m s|o|a|m] [-p] [-z] [-j frames_in_flight] [-g gpus_per_frame] [-u config] [--dump-scene file.ndtscene] [--raw file.f64] [--png]\n", argv[0]);
             return ch == 'h' ? 0 : 1;
         }
     }
@@ -352,6 +381,11 @@ int main(int argc, char **argv)
     job_opts.dims = dims; job_opts.width = width; job_opts.height = height; job_opts.depth = depth; job_opts.threads = threads;
     job_opts.aa_diff = aa_diff; job_opts.aa_depth = aa_depth; job_opts.stereo = stereo; job_opts.specular = specular;
     job_opts.want_depth = want_depth; job_opts.raw_path = raw_path; job_opts.samples = samples; job_opts.png = png;
+    job_opts.gpus = gpus > 1 ? gpus : 1;
+    if (job_opts.gpus > 1) {
+        printf("one frame over %d GPU contexts (%d device(s) visible)\n", job_opts.gpus, ndt_hip_device_count());
+        ndt_render_use_devices(job_opts.gpus);
+    }
     /* -j K: K frames in flight.  The scene program runs on this thread, frame after frame (it may
      * keep state between frames, ndt.c:1818-1825); everything after it -- bounding spheres, kd-tree,
      * upload, render, image files -- happens on K worker threads, each with its own GPU context.
@@ -362,7 +396,7 @@ int main(int argc, char **argv)
         workers = (pthread_t *)calloc((size_t)jobs, sizeof(pthread_t));
         queue_cap = jobs;
         queue = (frame_job *)calloc((size_t)queue_cap, sizeof(frame_job));
-        for (int k = 0; k < jobs; ++k) pthread_create(&workers[k], NULL, worker_main, NULL);
+        for (int k = 0; k < jobs; ++k) pthread_create(&workers[k], NULL, worker_main, (void *)(long)k);
     }
     double t_all = now_s();
     int rendered = 0;

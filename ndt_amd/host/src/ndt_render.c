@@ -2,8 +2,48 @@
  * render on the GPU through the C ABI of include/ndt_hip.h.  No CPU rendering exists here. */
 #include "ndt_host_internal.h"
 
-/* one GPU context (stream + workspace) per host thread: frames rendered from different threads overlap on the GPU */
-static __thread ndt_hip_ctx *g_ctx = NULL;
+/* GPU contexts (stream + workspace) of the calling host thread: frames rendered from different threads overlap on the
+ * GPU, or run on different GPUs (ndt_render_use_device); one frame may be spread over several (ndt_render_use_devices) */
+#define NDT_MAX_CTX 64
+static __thread ndt_hip_ctx *g_ctx[NDT_MAX_CTX];
+static __thread int g_n_ctx = 0;            /* contexts that exist */
+static __thread int g_want_ctx = 1;         /* contexts a frame is spread over */
+static __thread int g_first_device = 0;
+
+static void drop_contexts(void)
+{
+    for (int k = 0; k < g_n_ctx; ++k) ndt_hip_destroy(g_ctx[k]);
+    g_n_ctx = 0;
+}
+
+void ndt_render_use_device(int device)
+{
+    if (device < 0) device = 0;
+    if (g_want_ctx != 1 || g_first_device != device) drop_contexts();
+    g_want_ctx = 1;
+    g_first_device = device;
+}
+
+void ndt_render_use_devices(int n_contexts)
+{
+    if (n_contexts < 1) n_contexts = 1;
+    if (n_contexts > NDT_MAX_CTX) n_contexts = NDT_MAX_CTX;
+    if (g_want_ctx != n_contexts || g_first_device != 0) drop_contexts();
+    g_want_ctx = n_contexts;
+    g_first_device = 0;
+}
+
+/* the thread's contexts, created on first use: context k on device (first + k) mod device count */
+static int have_contexts(void)
+{
+    int n_dev = ndt_hip_device_count();
+    if (n_dev < 1) n_dev = 1;               /* ndt_hip_create then says why there is no device */
+    while (g_n_ctx < g_want_ctx) {
+        if (ndt_hip_create((g_first_device + g_n_ctx) % n_dev, &g_ctx[g_n_ctx]) != NDT_OK) return 0;
+        ++g_n_ctx;
+    }
+    return 1;
+}
 
 int ndt_render_image(scene *scn, int width, int height, int threads, int max_optic_depth, double *rgba)
 {
@@ -17,12 +57,9 @@ int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_d
     return ndt_render_image_full(scn, width, height, 1, threads, aa_diff, aa_depth, 0, 1, max_optic_depth, rgba, NULL);
 }
 
-/* everything render_image takes (ndt.c:900): samples = `-n`, stereo = the reference's stereo_mode (MONO ..
- * ANAGLYPH_3D), specular = specular_enabled (`-p` clears it), depth = the depth map of `-z` (width*height doubles) or NULL */
-int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
-                          int specular, int max_optic_depth, double *rgba, double *depth)
+static int render_any(scene *scn, int width, int height, int samples, int aa_diff, int aa_depth, int stereo, int specular,
+                      int max_optic_depth, int format, void *out, double *depth)
 {
-    (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
     char err[256];
     ndt_flat_builder fb;
     if (ndt_flatten_scene(scn, &fb, err, sizeof(err)) != 0) {
@@ -30,12 +67,10 @@ int ndt_render_image_full(scene *scn, int width, int height, int samples, int th
         ndt_flat_builder_free(&fb);
         return 0;
     }
-    int ok = 0;
-    if (!g_ctx && ndt_hip_create(0, &g_ctx) != NDT_OK) {
-        fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
-    } else if (ndt_hip_upload_scene(g_ctx, &fb.fs) != NDT_OK) {
-        fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
-    } else {
+    int ok = have_contexts();
+    for (int k = 0; ok && k < g_n_ctx; ++k)
+        if (ndt_hip_upload_scene(g_ctx[k], &fb.fs) != NDT_OK) ok = 0;
+    if (ok) {
         ndt_render_params p;
         memset(&p, 0, sizeof(p));
         p.width = width; p.height = height; p.max_optic_depth = max_optic_depth; p.samples = samples > 1 ? samples : 1;
@@ -46,9 +81,28 @@ int ndt_render_image_full(scene *scn, int width, int height, int samples, int th
             p.aa_diff = aa_diff;
             p.aa_depth = aa_depth;
         }
-        if (ndt_hip_render_depth(g_ctx, &p, rgba, depth, NULL) == NDT_OK) ok = 1;
-        else fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
+        if (depth)      /* the depth map comes from the one-context call (a map is not split over devices) */
+            ok = format == NDT_IMAGE_F64 && ndt_hip_render_depth(g_ctx[0], &p, (double *)out, depth, NULL) == NDT_OK;
+        else
+            ok = ndt_hip_render_multi(g_ctx, g_n_ctx, &p, format, out, NULL) == NDT_OK;
     }
+    if (!ok) fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
     ndt_flat_builder_free(&fb);
     return ok;
+}
+
+/* everything render_image takes (ndt.c:900): samples = `-n`, stereo = the reference's stereo_mode (MONO ..
+ * ANAGLYPH_3D), specular = specular_enabled (`-p` clears it), depth = the depth map of `-z` (width*height doubles) or NULL */
+int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
+                          int specular, int max_optic_depth, double *rgba, double *depth)
+{
+    (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
+    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_F64, rgba, depth);
+}
+
+int ndt_render_image_rgba8(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
+                           int specular, int max_optic_depth, unsigned char *rgba8)
+{
+    (void)threads;
+    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_RGBA8, rgba8, NULL);
 }

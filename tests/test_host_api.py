@@ -201,3 +201,35 @@ def test_png_at_1080p_is_the_references_image_byte_for_byte(driver, tmp_path):
     files = list((tmp_path / "images").rglob("*.png"))
     assert len(files) == 1
     assert np.array_equal(_read_png_rgba(str(files[0])), g.data["rgba8"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built")
+def test_one_frame_over_several_gpu_contexts_from_the_c_driver(driver, tmp_path):
+    """`ndt_hip -g N`: ONE frame spread over N GPU contexts by the C host (rows dealt cyclically like the reference's
+    MPI_MODE_ROW, ndt.c:812-820; context k on device k mod device count -- on a one-GPU box they share the card), each
+    context pushing its rows into the assembled frame.  BASELINE configs[3] (random 4-D, 3840x2160, -l 4) must come out
+    as the compiled reference's image, byte for byte, and `-g 1` / `-g 3` must agree on a frame whose height 3 does not divide."""
+    g = golden("c4_random4d_4k")
+    d = tmp_path / "g8"
+    d.mkdir()
+    cmd = [driver, "-s", os.path.join(REF_BIN, "random.so"), "-d", "4", "-f", "0", "-r", "4k", "-l", str(g.depth), "--png", "-g", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d))
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    assert "one frame over 8 GPU contexts" in r.stdout
+    files = list((d / "images").rglob("*.png"))
+    assert len(files) == 1
+    got = _read_png_rgba(str(files[0]))
+    mism = int((got != g.data["rgba8"]).sum())
+    print("4K over 8 contexts: %d of %d bytes differ from the reference's image" % (mism, got.size))
+    assert mism == 0
+    outs = []
+    for n in (1, 3):
+        d = tmp_path / ("n%d" % n)
+        d.mkdir()
+        cmd = [driver, "-s", os.path.join(REF_BIN, "hypercube.so"), "-d", "3", "-f", "0", "-r", "100x64", "-l", "16", "-g", str(n),
+               "--raw", str(d / "fb.f64")]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        outs.append((np.fromfile(str(d / "fb.f64")), [q.read_bytes() for q in sorted((d / "images").rglob("*.ppm"))]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and len(outs[0][1]) == 1
