@@ -54,6 +54,12 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
         return fail(NDT_E_DEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
     ndt_hip_ctx *ctx = new ndt_hip_ctx();
     ctx->device = device;
+    {
+        // which frame pipeline the context uses is fixed here, not looked up on the launch path
+        const char *pl = getenv("NDT_HIP_PIPELINE");
+        ctx->use_stream = !(pl && !strcmp(pl, "levels"));
+        ctx->stream_probe = getenv("NDT_HIP_STREAM_PROBE") != nullptr;
+    }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;

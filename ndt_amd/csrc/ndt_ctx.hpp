@@ -63,6 +63,12 @@ struct ndt_hip_ctx {
     long long ws_dims = 0;
     long long ws_slab_words = 0;
     int ws_nseg = 0;
+    // the streaming frame kernel (ndt_stream.hpp): its queues and counters live beside the workspace
+    bool use_stream = true;         // false: the bounce-synchronous pipeline (NDT_HIP_PIPELINE=levels at context creation)
+    StreamArgs sa{};
+    bool stream_probe = false;      // NDT_HIP_STREAM_PROBE at context creation: profiled frames log what every wavefront did
+    long long sa_cap = 0, sa_sh_cap = 0;
+    int sa_nseg = 0;
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
     void *d_shard = nullptr;        // ndt_hip_render_multi: this context's rows before they are pushed into the frame

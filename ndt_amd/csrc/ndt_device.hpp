@@ -71,6 +71,22 @@ NDT_DEV double ndt_rng_uniform(unsigned long long key, unsigned int k)
     return (double)(ndt_rng_mix(key + k) >> 11) * (1.0 / 9007199254740992.0);      // [0, 1)
 }
 
+// ------------------------------------------------------------------ libm
+// acos / asin / sin / cos / pow as real functions (one copy each per translation unit) instead of ocml's inline
+// expansions at every call site: the frame kernel had ~25 copies of acos alone (three per facet intersection, and
+// isect is itself instantiated three times), its code was 150 KB and most of its register spills sat around them.
+// Same ocml routines, same results.
+#ifndef NDT_INLINE_LIBM
+#define NDT_LIBM __device__ __attribute__((noinline))
+#else
+#define NDT_LIBM __device__ __forceinline__
+#endif
+NDT_LIBM double nd_acos(double x) { return acos(x); }
+NDT_LIBM double nd_asin(double x) { return asin(x); }
+NDT_LIBM double nd_sin(double x) { return sin(x); }
+NDT_LIBM double nd_cos(double x) { return cos(x); }
+NDT_LIBM double nd_pow(double x, double y) { return pow(x, y); }
+
 // ------------------------------------------------------------------ vectNd.h
 
 template <int N> NDT_DEV double v_dot(const double (&a)[N], const double (&b)[N])
@@ -141,7 +157,7 @@ template <int N> NDT_DEV double v_angle(const double (&a)[N], const double (&b)[
     double l1 = v_len<N>(a);
     double l2 = v_len<N>(b);
     double div = l1 * l2;
-    if (fabs(div) > NDT_EPS) return acos(dp / div);
+    if (fabs(div) > NDT_EPS) return nd_acos(dp / div);
     return -1;
 }
 template <int N> NDT_DEV double v_sum(const double (&a)[N])
@@ -180,9 +196,9 @@ template <int N> NDT_DEV void v_refract(const double (&u)[N], double (&nrm)[N], 
         theta_in = v_angle<N>(rev_u, nrm);
     }
     double theta_out;
-    double sin_out = sin(theta_in) / index;
+    double sin_out = nd_sin(theta_in) / index;
     if (sin_out <= 1.0)
-        theta_out = asin(sin_out);
+        theta_out = nd_asin(sin_out);
     else
         theta_out = NDT_PI - theta_in;
     v_unitize<N>(rev_n);
@@ -190,8 +206,8 @@ template <int N> NDT_DEV void v_refract(const double (&u)[N], double (&nrm)[N], 
     v_proj_unit<N>(u, rev_n, un);
     v_sub<N>(u, un, np);
     v_unitize<N>(np);
-    double rn = cos(theta_out);
-    double rp = sin(theta_out);
+    double rn = nd_cos(theta_out);
+    double rp = nd_sin(theta_out);
     if (un_dot < 0)
         v_scale<N>(nrm, rn, ref_n);
     else
@@ -711,13 +727,22 @@ template <int MW> struct VisitMask {
     unsigned long long w[MW > 0 ? MW : 1];
     unsigned long long *ext;
     int ext_stride;
+    // MW == 0, masks of up to 128 words (8192 items): which words of the slab this ray has written.  A word that has
+    // not been written yet counts as zero, so a new ray costs two register moves instead of `words` stores to the slab
+    // (103 words = 0.8 KB per ray on the 8-D hypercube: more than the whole algorithmic ray record).
+    unsigned long long live0, live1;
+    bool lazy;
     NDT_DEV void clear(int words)
     {
         if (MW > 0) {
 #pragma unroll
             for (int i = 0; i < MW; ++i) w[i] = 0ull;
         } else {
-            for (int i = 0; i < words; ++i) ext[(size_t)i * ext_stride] = 0ull;
+            lazy = words <= 128;
+            live0 = 0ull;
+            live1 = 0ull;
+            if (!lazy)
+                for (int i = 0; i < words; ++i) ext[(size_t)i * ext_stride] = 0ull;
         }
     }
     // returns true when `id` was already visited; marks it otherwise
@@ -736,7 +761,15 @@ template <int MW> struct VisitMask {
             }
             return seen;
         } else {
-            unsigned long long cur = ext[(size_t)word * ext_stride];
+            bool written = true;
+            if (lazy) {
+                const unsigned long long wb = 1ull << (word & 63);
+                written = (((word < 64) ? live0 : live1) & wb) != 0ull;
+                if (word < 64) live0 |= wb;
+                else live1 |= wb;
+            }
+            unsigned long long cur = 0ull;
+            if (written) cur = ext[(size_t)word * ext_stride];
             if (cur & bit) return true;
             ext[(size_t)word * ext_stride] = cur | bit;
             return false;

@@ -2,6 +2,7 @@
 // bounce loop, bottom-up resolve, per-primary colour.  render_image (ndt.c:900) for the deterministic path is one
 // such pass; recursive anti-aliasing and the sampled paths call it once per level / round.
 #include "ndt_ctx.hpp"
+#include <stddef.h>
 
 void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
 {
@@ -11,6 +12,9 @@ void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
     ctx->ws_slab_words = 0;
     ctx->ws_dims = 0;
     ctx->ws_nseg = 0;
+    memset(&ctx->sa, 0, sizeof(ctx->sa));
+    ctx->sa_cap = ctx->sa_sh_cap = 0;
+    ctx->sa_nseg = 0;
 }
 
 // ------------------------------------------------------------------ workspace
@@ -81,6 +85,41 @@ int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap
     return NDT_OK;
 }
 
+// The queues and counters of the streaming frame kernel for the current workspace: one fill counter, one lighting
+// counter and one ring entry per node batch, the same per shadow batch of every light's segment, a parent and a
+// wait count per node, an owner per shadow slot.  (Allocated with the workspace: free_workspace releases them.)
+static int ensure_stream_args(ndt_hip_ctx *ctx)
+{
+    const Workspace &ws = ctx->ws;
+    const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
+    if (ctx->sa.ctl && ctx->sa_cap == ws.cap && ctx->sa_sh_cap == ws.sh_cap && ctx->sa_nseg == n_seg) return NDT_OK;
+    StreamArgs &sa = ctx->sa;
+    // rings have room for a ticket per wavefront beyond the last entry (a wavefront's ticket may name a slot that is never written)
+    const long long margin = NDT_STREAM_LOG_WAVES;
+    const long long node_batches = ws.cap / 64 + margin;
+    const long long seg_cap = (ws.sh_cap / n_seg) & ~63LL;
+    const long long sh_batches = (long long)n_seg * (seg_cap / 64) + margin;
+    int rc;
+    if ((rc = ws_alloc(ctx, &sa.ctl, 1))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.node_fill, (size_t)node_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_pending, (size_t)node_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_fill, (size_t)sh_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sec_ring, (size_t)NDT_PRIM_SHARDS * node_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_ring, (size_t)sh_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.fin_ring, (size_t)node_batches))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.parent, (size_t)ws.cap))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.pend, (size_t)ws.cap))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sowner, (size_t)n_seg * seg_cap))) return rc;
+    if (ctx->stream_probe && (rc = ws_alloc(ctx, &sa.wave_log, (size_t)24 * NDT_STREAM_LOG_WAVES))) return rc;
+    sa.n_seg = n_seg;
+    sa.seg_cap = (int)seg_cap;
+    sa.node_batches = (int)node_batches;
+    ctx->sa_cap = ws.cap;
+    ctx->sa_sh_cap = ws.sh_cap;
+    ctx->sa_nseg = n_seg;
+    return NDT_OK;
+}
+
 // ------------------------------------------------------------------ dimension-independent kernels
 
 // Everything a frame needs reset, in one launch (five small copies / fills of 10 us each before): node tail and
@@ -120,6 +159,58 @@ __global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, 
     done[3] = (unsigned long long)shadow;
     done[4] = (unsigned long long)used;
     done[5] = ref;
+    __threadfence_system();
+    __hip_atomic_store(&done[7], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The streaming pipeline's frame reset: control block, fill / lighting counters and rings of the batches the frame can
+// have, the reference-ray partial sums.  (Sized by the pool, not by the frame: a few MB of zeros.)
+__global__ void __launch_bounds__(256) k_stream_init(Workspace ws, StreamArgs sa, long long node_batches, long long sh_batches)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    // the control block: zeros, except the node tail (the pool behind the primaries is free) and the primaries' share of
+    // every shard's outstanding count -- written by the thread that owns the word, so that no zero can land on top of it
+    int *ctl = reinterpret_cast<int *>(sa.ctl);
+    const int prim_batches = sa.n_primary >> 6;
+    for (long long k = i; k < (long long)(sizeof(StreamCtl) / sizeof(int)); k += stride) {
+        int v = 0;
+        if (k == (long long)(offsetof(StreamCtl, node_tail) / sizeof(int))) v = sa.n_primary;
+        for (int sh = 0; sh < NDT_PRIM_SHARDS; ++sh)
+            if (k == (long long)((offsetof(StreamCtl, outstanding) + sh * sizeof(StreamWord)) / sizeof(int)))
+                v = 128 * ((prim_batches + NDT_PRIM_SHARDS - 1 - sh) / NDT_PRIM_SHARDS);
+        ctl[k] = v;
+    }
+    for (long long k = i; k < node_batches; k += stride) {
+        sa.node_fill[k] = 0;
+        sa.sh_pending[k] = 0;
+        for (int sh = 0; sh < NDT_PRIM_SHARDS; ++sh) sa.sec_ring[(long long)sh * node_batches + k] = 0;
+        sa.fin_ring[k] = 0;
+    }
+    for (long long k = i; k < sh_batches; k += stride) {
+        sa.sh_fill[k] = 0;
+        sa.sh_ring[k] = 0;
+    }
+    for (long long k = i; k < 64 * 8; k += stride) ws.ref_rays[k] = 0ull;
+    for (long long k = i; k < 4; k += stride) ws.counters[k] = 0;
+}
+
+// The streaming pipeline's closing record, in host-visible memory (the host polls the tag):
+//   [0] node tail  [1] overflow flags  [2] abort  [3] shadow rays  [4] deepest bounce + 1  [5] reference-equivalent rays
+//   [6] children  [7] tag
+__global__ void k_stream_done(Workspace ws, StreamArgs sa, unsigned long long *done, unsigned long long tag)
+{
+    const int lane = threadIdx.x;
+    unsigned long long ref = ws.ref_rays[8 * lane];
+    for (int d = 32; d > 0; d >>= 1) ref += __shfl_xor(ref, d, 64);
+    if (lane != 0) return;
+    const StreamCtl *c = sa.ctl;
+    done[0] = (unsigned long long)(long long)c->node_tail.v;
+    done[1] = (unsigned long long)(long long)c->overflow.v;
+    done[2] = (unsigned long long)(long long)(c->abort.v | (c->timeout_where.v << 8));
+    done[3] = (unsigned long long)(long long)c->n_shadow.v;
+    done[4] = (unsigned long long)(long long)(c->max_level.v + 1);
+    done[5] = ref;
+    done[6] = (unsigned long long)(long long)c->n_children.v;
     __threadfence_system();
     __hip_atomic_store(&done[7], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -336,6 +427,135 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     }
 
     const NdtKernelTable *kt = ctx->kt;
+    if (ctx->use_stream) {
+        // ---- the streaming pipeline: one persistent launch for the whole ray tree (ndt_stream.hpp)
+        const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            // every light's shadow segment can hold one ray per node
+            if (sh_cap < cap * n_seg) sh_cap = cap * n_seg;
+            if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
+            int rc = ensure_workspace(ctx, cap, sh_cap);
+            if (rc) return rc;
+            if ((rc = ensure_stream_args(ctx))) return rc;
+            Workspace ws = ctx->ws;
+            StreamArgs sa = ctx->sa;
+            sa.n_primary = rg.n_primary;
+            unsigned int *wave_log = sa.wave_log;
+            if (!prof) sa.wave_log = nullptr;
+            else if (wave_log) HIP_TRY(hipMemsetAsync(wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
+            hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+            if (prof) {
+                ev_begin = get_event(ctx, 0);
+                ev_end = get_event(ctx, 1);
+                ev_k0 = get_event(ctx, 2);
+                ev_k1 = get_event(ctx, 3);
+            }
+            const unsigned long long tag = ++ctx->frame_tag;
+            const long long node_batches = sa.node_batches, sh_batches = (long long)sa.n_seg * (sa.seg_cap / 64) + NDT_STREAM_LOG_WAVES;
+            if (prof)
+                hipExtLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, sa, node_batches, sh_batches);
+            else
+                hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, node_batches, sh_batches);
+            kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+            kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
+            hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                               rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+            if (prof)
+                hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
+            else
+                hipLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, ws, sa, ctx->d_done, tag);
+            HIP_TRY(hipGetLastError());
+            {
+                const double t_wait = wall_s();
+                while (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) {
+                    if (wall_s() - t_wait > 30.0) {
+                        HIP_TRY(hipStreamSynchronize(s));
+                        if (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "the frame never completed");
+                    }
+                }
+            }
+            if (prof) HIP_TRY(hipEventSynchronize(ev_end));
+            const int overflow = (int)(long long)ctx->h_done[1], aborted = (int)(long long)ctx->h_done[2];
+            if (overflow != 0) {
+                if (overflow & 1) cap *= 2;
+                if (overflow & 2) sh_cap *= 2;
+                continue;
+            }
+            if (aborted != 0)
+                return fail(NDT_E_STATE, "the frame kernel gave up (abort %d, where %d): a work item never arrived", aborted & 0xff, aborted >> 8);
+            st = ndt_render_stats{};
+            st.rays_primary = n_pixels;
+            st.rays_secondary = (long long)ctx->h_done[6];
+            st.rays_shadow = (long long)ctx->h_done[3];
+            st.rays_ref_equiv = (long long)ctx->h_done[5];
+            st.levels = (int)ctx->h_done[4];
+            st.trace_launches = 1;
+            st.node_capacity = ws.cap;
+            if (prof) {
+                float km = 0, fm = 0;
+                HIP_TRY(hipEventElapsedTime(&km, ev_k0, ev_k1));
+                HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
+                st.trace_ms = km;
+                st.frame_ms = fm;
+                if (wave_log) {
+                    // NDT_HIP_STREAM_PROBE: what every wavefront of the frame kernel did and when (100 MHz ticks)
+                    std::vector<unsigned int> log((size_t)24 * NDT_STREAM_LOG_WAVES);
+                    if (hipMemcpy(log.data(), wave_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+                        unsigned long long n[4] = { 0, 0, 0, 0 }, t[3] = { 0, 0, 0 }, parts[5] = { 0, 0, 0, 0, 0 };
+                        int waves = 0, busy_waves = 0;
+                        unsigned int t0 = 0, max_items = 0;
+                        bool any = false;
+                        for (int w = 0; w < NDT_STREAM_LOG_WAVES; ++w) {
+                            const unsigned int *q = &log[(size_t)24 * w];
+                            if (!q[9]) continue;
+                            if (!any || (int)(q[10] - t0) < 0) t0 = q[10];
+                            any = true;
+                        }
+                        double first_item = 1e30, last_item = 0, last_exit = 0, start_spread = 0;
+                        int hist[32] = { 0 };
+                        for (int w = 0; w < NDT_STREAM_LOG_WAVES; ++w) {
+                            const unsigned int *q = &log[(size_t)24 * w];
+                            if (!q[9]) continue;
+                            ++waves;
+                            const unsigned int items = q[0] + q[1] + q[2];
+                            if (items) ++busy_waves;
+                            if (items > max_items) max_items = items;
+                            for (int k = 0; k < 4; ++k) n[k] += q[k];
+                            for (int k = 0; k < 3; ++k) t[k] += q[4 + k];
+                            for (int k = 0; k < 5; ++k) parts[k] += q[12 + k];
+                            const double off = (q[10] - t0) / 100.0;
+                            if (off > start_spread) start_spread = off;
+                            if (q[7] && off + q[7] / 100.0 < first_item) first_item = off + q[7] / 100.0;
+                            if (off + q[8] / 100.0 > last_item) last_item = off + q[8] / 100.0;
+                            if (off + q[9] / 100.0 > last_exit) last_exit = off + q[9] / 100.0;
+                            int bin = (int)((off + q[8] / 100.0) / (km * 1000.0 / 32.0 + 1e-9));
+                            ++hist[bin < 0 ? 0 : bin > 31 ? 31 : bin];
+                        }
+                        std::string line;
+                        for (int b = 0; b < 32; ++b) {
+                            char buf[16];
+                            snprintf(buf, sizeof buf, " %d", hist[b]);
+                            line += buf;
+                        }
+                        fprintf(stderr, "ndt_hip: frame kernel %.3f ms: %d wavefronts (%d with work, at most %u items each) started within %.1f us; "
+                                        "node batches %llu (%.1f us each), shadow batches %llu (%.1f us each), lighting batches %llu (%.1f us each), "
+                                        "idle rounds %llu; first item at %.1f us, last item done at %.1f us, last exit at %.1f us; "
+                                        "wavefronts by the 32nd of the kernel in which they finished their last item:%s\n",
+                                km, waves, busy_waves, max_items, start_spread, n[0], n[0] ? t[0] / 100.0 / n[0] : 0.0, n[1],
+                                n[1] ? t[1] / 100.0 / n[1] : 0.0, n[2], n[2] ? t[2] / 100.0 / n[2] : 0.0, n[3], first_item, last_item, last_exit,
+                                line.c_str());
+                        fprintf(stderr, "ndt_hip:    per item: looking for work %.1f us (all kinds); node + shadow items: loading the rays %.1f us; trace_kd: node "
+                                        "batches %.1f us, shadow batches %.1f us; colours up the tree + counters %.1f us (node and lighting batches)\n",
+                                (n[0] + n[1] + n[2]) ? parts[0] / 100.0 / (n[0] + n[1] + n[2]) : 0.0,
+                                (n[0] + n[1]) ? parts[1] / 100.0 / (n[0] + n[1]) : 0.0, n[0] ? (parts[2] - parts[3]) / 100.0 / n[0] : 0.0,
+                                n[1] ? parts[3] / 100.0 / n[1] : 0.0, (n[0] + n[2]) ? parts[4] / 100.0 / (n[0] + n[2]) : 0.0);
+                    }
+                }
+            }
+            return NDT_OK;
+        }
+        return fail(NDT_E_NOMEM, "ray-tree workspace kept overflowing");
+    }
     for (int attempt = 0; attempt < 8; ++attempt) {
         if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
         int rc = ensure_workspace(ctx, cap, sh_cap);

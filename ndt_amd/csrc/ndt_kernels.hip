@@ -266,6 +266,8 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     VisitMask<MW> mask;
     mask.ext = nullptr;
     mask.ext_stride = 0;
+    mask.live0 = mask.live1 = 0ull;
+    mask.lazy = false;
     if (MW == 0) {
         const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         mask.ext = ws.mask_slab + lane_slot;
@@ -975,7 +977,7 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
             }
             double angle = v_angle<N>(nrm, light_vec);      // ndt.c:263
             if (angle > NDT_PI / 2.0) angle = NDT_PI - angle;
-            const double light_scale = cos(angle) / ss.ldist2;
+            const double light_scale = nd_cos(angle) / ss.ldist2;
             if (!transparent) {
                 cr += hit_r * lr_ * light_scale;
                 cg += hit_g * lg_ * light_scale;
@@ -989,7 +991,7 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
                 v_unitize<N>(rev_look);
                 double rv = v_dot<N>(light_ref, rev_look);
                 rv = (0 > rv) ? 0 : rv;                     // MAX(0,rv), image.h:31
-                const double rvn = pow(rv, 50.0);
+                const double rvn = nd_pow(rv, 50.0);
                 const double gb = (lg_ > lb_) ? lg_ : lb_;
                 const double max_light = (lr_ > gb) ? lr_ : gb;
                 cr += hitr_r * lr_ / max_light * rvn;

@@ -121,20 +121,33 @@ struct TraceJob {
 // nodes to trace and shade, a batch of 64 shadow rays to trace, a batch of 64 nodes whose shadow answers are all in
 // to light -- from device-side queues, and produce the items that depend on theirs.  Nothing waits for a bounce to
 // finish: a wavefront that runs out of one kind of work takes another.
+// One hot word of the control block.  The words are 4352 bytes apart: memory is interleaved over the L2 / HBM channels
+// in blocks of a few KB, so a control block of consecutive cache lines lives in ONE channel and every counter, head and
+// tail of the frame is served by it, one after the other (~100 operations per microsecond: with 600 k of them a frame
+// the whole kernel ran at the speed of that channel -- 6 ms whatever the number of wavefronts).
+struct StreamWord {
+    int v;
+    int _pad[1087];
+};
 struct StreamCtl {
-    // every hot word on a 64-byte line of its own
-    int node_tail, _p0[15];         // next free node slot; starts at n_primary (a multiple of 64)
-    int nodes_done, _p1[15];        // nodes (in whole batches) whose trace + shading is complete
-    int finish_done, _p2[15];       // nodes (in whole batches) whose lighting is complete
-    int sec_head, _p3[15], sec_tail, _p4[15];   // ring of ready batches of secondary nodes
-    int sh_head, _p5[15], sh_tail, _p6[15];     // ring of ready batches of shadow rays
-    int fin_head, _p7[15], fin_tail, _p8[15];   // ring of node batches ready for lighting
-    int prim_head[8 * 16];          // sharded heads of the primaries' batches (batch b belongs to shard b % 8)
-    int seg_tail[64 * 16];          // next free slot of every light's shadow segment (one line each)
-    int abort, _p9[15];             // != 0: every wavefront leaves (1 pool overflow, 2 timeout)
-    int overflow;                   // 1 node pool, 2 shadow segment
-    int n_children, n_shadow, max_level;        // statistics
-    int timeout_where, _p10[11];
+    StreamWord node_tail;           // next free node slot; starts at n_primary (a multiple of 64)
+    // What is still to do, in node slots, per shard (batch nb belongs to shard nb % 8): +2 for every slot reserved (primaries:
+    // set at the frame's start), -1 per slot when its batch has been traced and shaded, -1 when its lighting is done (or it
+    // needs none).  All eight zero, with the node tail unchanged around the reading: the frame is complete.
+    StreamWord outstanding[8];
+    // Ready batches of secondary nodes: one ring per shard (workgroup w pushes to and pops from shard w % 8, and looks at
+    // the other shards only when it has nothing to do).  v = tail (low half) and head (high half) of the ring in ONE word:
+    // "is there something" is one load, a push one 64-bit add of 1, a pop one add of 1 << 32.
+    struct { unsigned long long v; int _pad[1086]; } sec[8];
+    // Ready batches of shadow rays / of nodes to light: one ring each.  A wavefront ALWAYS holds a ticket (a slot number)
+    // of each and polls that slot -- an address of its own -- so nobody ever reads head or tail.
+    StreamWord sh_head, sh_tail;
+    StreamWord fin_head, fin_tail;
+    StreamWord prim_head[8];        // sharded heads of the primaries' batches (batch b belongs to shard b % 8)
+    StreamWord seg_tail[64];        // next free slot of every light's shadow segment
+    StreamWord abort;               // != 0: every wavefront leaves (1 pool overflow, 2 timeout)
+    StreamWord overflow;            // 1 node pool, 2 shadow segment
+    StreamWord n_children, n_shadow, max_level, timeout_where;     // statistics (every wavefront adds its own once, when it leaves)
 };
 #define NDT_PRIM_SHARDS 8
 struct StreamArgs {
@@ -142,13 +155,16 @@ struct StreamArgs {
     int *node_fill;         // [cap / 64]      slots of a node batch that have been written
     int *sh_pending;        // [cap / 64]      shadow rays of a node batch that are not answered yet
     int *sh_fill;           // [n_seg][seg_cap / 64]
-    int *sec_ring, *sh_ring, *fin_ring;     // entries: id + 1, 0 = not written yet
+    int *sec_ring, *sh_ring, *fin_ring;     // entries: id + 1, 0 = not written yet; sec_ring: [8 shards][cap / 64]
     int *parent, *pend;     // [cap]  the node a node reports to; what a node still waits for (own lighting + children)
     int *sowner;            // [n_seg * seg_cap]  the node a shadow ray belongs to, -1 = padding slot
     int n_seg;
     int seg_cap;            // slots per light segment (multiple of 64)
     int n_primary;          // multiple of 64
+    int node_batches;       // cap / 64: entries per shard of sec_ring
+    unsigned int *wave_log; // NDT_HIP_STREAM_PROBE: 16 words per wavefront (what it did and when), else nullptr
 };
+#define NDT_STREAM_LOG_WAVES 16384
 
 // One table per compiled dimension.
 struct NdtKernelTable {

@@ -36,6 +36,14 @@
 
 // ------------------------------------------------------------------ coherent loads / stores, drained publishes
 
+#ifdef NDT_STREAM_PLAIN   /* experiment only: what the coherent accesses cost (results may be stale) */
+NDT_DEV double cld(const double *p) { return *p; }
+NDT_DEV void cst(double *p, double v) { *p = v; }
+NDT_DEV int cldi(const int *p) { return *(const volatile int *)p; }
+NDT_DEV void csti(int *p, int v) { *p = v; }
+NDT_DEV unsigned long long cldu(const unsigned long long *p) { return *p; }
+NDT_DEV void cstu(unsigned long long *p, unsigned long long v) { *p = v; }
+#else
 NDT_DEV double cld(const double *p)
 {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)),
@@ -53,6 +61,7 @@ NDT_DEV unsigned long long cldu(const unsigned long long *p)
     return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 NDT_DEV void cstu(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 template <int K> NDT_DEV void cload_soa(const double *base, long long g, double (&r)[K])
 {
     const double *t = base + (g >> 6) * (long long)(K * 64) + (g & 63);
@@ -75,43 +84,120 @@ NDT_DEV int wave_sum(int x)
     return x;
 }
 
-// ------------------------------------------------------------------ rings
+// ------------------------------------------------------------------ queues
+//
+// Everything here is about NOT having hot words: one address takes ~88 atomics (or agent-scope loads) per microsecond,
+// a frame has 90 000 work items, and a memory channel busy with one word makes every other access it serves wait
+// (the first version of this kernel read four heads and tails before every item and ran at the speed of those words:
+// 4 ms a frame whatever the number of wavefronts).
 
-// Several lanes may push at once (each gets a slot of its own).  The slot is reserved first and written second: a
-// consumer that wins slot h waits for its entry to become non-zero.
+NDT_DEV unsigned long long cld64(const unsigned long long *p) { return cldu(p); }
+
+// ---- secondary node batches: one ring per shard
+NDT_DEV void sec_push(const StreamArgs &sa, int shard, int nb)
+{
+    const unsigned long long old = atomicAdd(&sa.ctl->sec[shard].v, 1ull);
+    csti(sa.sec_ring + (long long)shard * (sa.node_batches) + (int)(old & 0xffffffffull), nb + 1);
+}
+// a ticket of shard `shard` if its ring is not empty (lane 0 only)
+NDT_DEV int sec_ticket(const StreamArgs &sa, int shard)
+{
+    const unsigned long long v = cld64(&sa.ctl->sec[shard].v);
+    if ((unsigned int)(v >> 32) >= (unsigned int)(v & 0xffffffffull)) return -1;
+    return (int)(atomicAdd(&sa.ctl->sec[shard].v, 1ull << 32) >> 32);
+}
+// One secondary node batch for the wavefront (every lane calls; lane 0 works).  A ticket whose slot is still empty (two
+// wavefronts saw the same last entry) stays in tk / tk_shard and is looked at again next time.  steal: also look at
+// the other shards (a wavefront that has nothing else to do).
+NDT_DEV bool sec_pop(const StreamArgs &sa, int home, bool steal, int &tk, int &tk_shard, int &id)
+{
+    int got = -1, t = tk, ts = tk_shard;
+    if (__lane_id() == 0) {
+        if (t < 0) {
+            t = sec_ticket(sa, home);
+            ts = home;
+            for (int k = 1; steal && t < 0 && k < NDT_PRIM_SHARDS; ++k) {
+                ts = (home + k) % NDT_PRIM_SHARDS;
+                t = sec_ticket(sa, ts);
+            }
+        }
+        if (t >= 0) {
+            const int e = cldi(sa.sec_ring + (long long)ts * sa.node_batches + t);
+            if (e != 0) {
+                got = e - 1;
+                t = -1;
+            }
+        }
+    }
+    tk = __shfl(t, 0, 64);
+    tk_shard = __shfl(ts, 0, 64);
+    id = __shfl(got, 0, 64);
+    return id >= 0;
+}
+
+// ---- shadow batches, lighting batches: one ring each; the wavefront always holds a ticket
 NDT_DEV void ring_push(int *tail, int *ring, int id)
 {
     const int slot = atomicAdd(tail, 1);
     csti(ring + slot, id + 1);
 }
-
-// One item for the wavefront (every lane calls; lane 0 works): false when the ring is empty right now.
-NDT_DEV bool ring_pop(int *head, const int *tail, const int *ring, int &id, StreamCtl *ctl)
+// (every lane calls; lane 0 works) the item in the wavefront's slot, if it has been written; the next ticket is taken at
+// once.  The FIRST ticket is taken when the wavefront first looks at the ring (ticket < 0) -- not at the start of the
+// kernel, where 2 000 wavefronts taking two tickets each kept two words busy for 23 us, and not a fixed one per wavefront
+// number either: a ticket must belong to a wavefront that is running (several contexts may share the GPU, and a workgroup
+// that has not been scheduled yet would sit on the items pushed into its slots).
+NDT_DEV bool ring_pop(int *head, const int *ring, int &ticket, int &id)
 {
-    int got = -1;
+    int got = -1, tk = ticket;
     if (__lane_id() == 0) {
-        int h = cldi(head);
-        while (h < cldi(tail)) {
-            const int old = atomicCAS(head, h, h + 1);
-            if (old == h) {
-                int e = cldi(ring + h);
-                for (unsigned spin = 0; e == 0 && spin < (1u << 20); ++spin) {
-                    __builtin_amdgcn_s_sleep(2);
-                    e = cldi(ring + h);
-                }
-                if (e == 0) {           // the producer never wrote its slot: something is badly wrong; everyone out
-                    atomicMax(&ctl->abort, 2);
-                    ctl->timeout_where = 1;
-                }
-                got = e - 1;
-                break;
-            }
-            h = old;
+        if (tk < 0) tk = atomicAdd(head, 1);
+        const int e = cldi(ring + tk);
+        if (e != 0) {
+            got = e - 1;
+            tk = atomicAdd(head, 1);
         }
     }
+    ticket = __shfl(tk, 0, 64);
     id = __shfl(got, 0, 64);
     return id >= 0;
 }
+
+// ------------------------------------------------------------------ hit point and normal, out of line
+// isect<N, true> as ONE real function for the two places of the frame kernel that re-run a primitive for its hit point
+// and normal (shading: the primitive the traversal returned; lighting: the primitive the shadow ray met).  Inlined, each
+// copy was ~10 KB of code in the middle of a function that already holds four N-vectors: the arguments now travel through
+// the wavefront's private memory (4N doubles per call, twice per node) and the register allocator sees two small
+// functions instead of one that cannot fit.
+struct VecPair {
+    double a[N], b[N];
+};
+#ifndef NDT_STREAM_INLINE_ISECT
+// (arguments and results by value: they travel in registers; by pointer the caller's vectors would live in private memory)
+__device__ __attribute__((noinline)) VecPair isect_full_call(const double *blob, const SceneDesc *sd, int prim, VecPair ray)
+{
+    VecPair out;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { out.a[c] = 0.0; out.b[c] = 0.0; }
+    isect<N, true>(blob, *sd, prim, ray.a, ray.b, out.a, out.b);
+    return out;
+}
+NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
+                        double (&nrm)[N])
+{
+    VecPair ray;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { ray.a[c] = o[c]; ray.b[c] = v[c]; }
+    const VecPair out = isect_full_call(blob, sd, prim, ray);
+#pragma unroll
+    for (int c = 0; c < N; ++c) { hit[c] = out.a[c]; nrm[c] = out.b[c]; }
+}
+#else
+NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
+                        double (&nrm)[N])
+{
+    isect<N, true>(blob, *sd, prim, o, v, hit, nrm);
+}
+#endif
 
 // ------------------------------------------------------------------ the ray tree, bottom-up
 
@@ -180,8 +266,8 @@ NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace
 // ------------------------------------------------------------------ lighting of one node batch
 
 // Second half of apply_lights (ndt.c:217-310) for the 64 nodes of batch nb: shade_finish_node with coherent accesses,
-// then the nodes' colours start their way up the tree.  Every lane of the wavefront calls.
-NDT_DEV void stream_light_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
+// returns whether this lane's node was lit (its colour then starts its way up the tree).  Every lane of the wavefront calls.
+NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
                                 const StreamArgs &sa, int nb)
 {
     const long long g = (long long)nb * 64 + __lane_id();
@@ -236,13 +322,13 @@ NDT_DEV void stream_light_batch(const double *blob, const double *mat, const Sce
             } else {
                 if (sobj != obj) continue;                  // ndt.c:217
                 double light_hit[N];
-                isect<N, true>(blob, sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                isect_full(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
                 const double dist = v_dist<N>(hit, light_hit);
                 if (dist > NDT_EPS) continue;               // ndt.c:225
             }
             double angle = v_angle<N>(nrm, light_vec);      // ndt.c:263
             if (angle > NDT_PI / 2.0) angle = NDT_PI - angle;
-            const double light_scale = cos(angle) / ss.ldist2;
+            const double light_scale = nd_cos(angle) / ss.ldist2;
             if (!transparent) {
                 cr += hit_r * lr_ * light_scale;
                 cg += hit_g * lg_ * light_scale;
@@ -256,7 +342,7 @@ NDT_DEV void stream_light_batch(const double *blob, const double *mat, const Sce
                 v_unitize<N>(rev_look);
                 double rv = v_dot<N>(light_ref, rev_look);
                 rv = (0 > rv) ? 0 : rv;                     // MAX(0,rv), image.h:31
-                const double rvn = pow(rv, 50.0);
+                const double rvn = nd_pow(rv, 50.0);
                 const double gb = (lg_ > lb_) ? lg_ : lb_;
                 const double max_light = (lr_ > gb) ? lr_ : gb;
                 cr += hitr_r * lr_ / max_light * rvn;
@@ -270,8 +356,7 @@ NDT_DEV void stream_light_batch(const double *blob, const double *mat, const Sce
         csti(ws.count + g, 1 + n_shadow);
     }
     drain();
-    complete_up(mat, sd, ws, sa, rg.specular, (int)g, shaded);
-    if (__lane_id() == 0) atomicAdd(&sa.ctl->finish_done, 64);
+    return shaded;          // the caller sends the lit nodes' colours up the tree (complete_up) and counts the batch's lighting done
 }
 
 // ------------------------------------------------------------------ shading of one node batch (after its trace_kd)
@@ -281,10 +366,19 @@ NDT_DEV void stream_light_batch(const double *blob, const double *mat, const Sce
 // and normal, background colour, children, shadow rays -- shade_emit_node with per-wavefront reservations (the
 // wavefronts of a persistent launch are not in step, so there is no workgroup to share a reservation with; they also
 // do not all arrive at the counters at once).  Every lane of the wavefront calls.
+struct WaveStats {          // what a wavefront adds to the frame's statistics when it leaves (not per item: hot words)
+    int children, shadow, max_level;
+};
+
 NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
                                 const StreamArgs &sa, int nb, bool valid, int depth_left, const double (&src)[N],
-                                const double (&look)[N], int obj, int prim)
+                                const double (&look)[N], int obj, int prim, WaveStats &stats, int home, int &up_node, bool &up_active,
+                                bool &light_now, bool &any_shaded)
 {
+    up_node = 0;
+    up_active = false;
+    light_now = false;
+    any_shaded = false;
     StreamCtl *ctl = sa.ctl;
     const int lane = __lane_id();
     const long long g = (long long)nb * 64 + lane;
@@ -293,7 +387,7 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
     if (valid) {
         if (obj >= 0) {
             // the hit point and normal trace_kd would have returned: re-run the one primitive that won the traversal
-            isect<N, true>(blob, sd, prim, src, look, hit, nrm);
+            isect_full(blob, &sd, prim, src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && g < sa.n_primary) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;     // ndt.c:366-370
@@ -380,14 +474,14 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
         const int n_refl = __popcll(v_refl), total = n_refl + __popcll(v_refr);
         int base = 0;
         if (total > 0) {
-            if (lane == 0) base = atomicAdd(&ctl->node_tail, total);
-            if (lane == 1) atomicAdd(&ctl->n_children, total);
+            if (lane == 0) base = atomicAdd(&ctl->node_tail.v, total);
+            stats.children += total;
             base = __shfl(base, 0, 64);
             if ((long long)base + total > ws.cap) {
                 // node pool overflow: flag it (the host renders the frame again with a larger pool); everyone leaves
                 if (lane == 0) {
-                    atomicOr(&ctl->overflow, 1);
-                    atomicMax(&ctl->abort, 1);
+                    atomicOr(&ctl->overflow.v, 1);
+                    atomicMax(&ctl->abort.v, 1);
                 }
                 return;
             }
@@ -395,13 +489,13 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
         int my_base = 0;
         n_sh_batch = wave_sum(my_total);
         if (my_total > 0) {
-            my_base = atomicAdd(&ctl->seg_tail[lane * 16], my_total);
+            my_base = atomicAdd(&ctl->seg_tail[lane].v, my_total);
             if ((long long)my_base + my_total > sa.seg_cap) {
-                atomicOr(&ctl->overflow, 2);
-                atomicMax(&ctl->abort, 1);
+                atomicOr(&ctl->overflow.v, 2);
+                atomicMax(&ctl->abort.v, 1);
             }
         }
-        if (lane == 63 && n_sh_batch > 0) atomicAdd(&ctl->n_shadow, n_sh_batch);
+        stats.shadow += n_sh_batch;
         if (__ballot(my_total > 0 && (long long)my_base + my_total > sa.seg_cap) != 0ull) return;
         // ---- the children
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -436,7 +530,7 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
             int lvl = (want_refl || want_refr) ? rg.max_depth - depth_next : 0;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) lvl = max(lvl, __shfl_xor(lvl, d, 64));
-            if (lane == 2) atomicMax(&ctl->max_level, lvl);
+            stats.max_level = max(stats.max_level, lvl);
         }
         // ---- the shadow rays, into their segments
         seg = 0;
@@ -473,8 +567,9 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
             const int kb = (base >> 6) + lane;
             if (kb <= ((base + total - 1) >> 6)) {
                 const int lo = base > kb * 64 ? base : kb * 64, hi = base + total < (kb + 1) * 64 ? base + total : (kb + 1) * 64;
+                atomicAdd(&ctl->outstanding[kb % NDT_PRIM_SHARDS].v, 2 * (hi - lo));      // performed before our own "done" below (drain)
                 const int old = atomicAdd(sa.node_fill + kb, hi - lo);
-                if (old + (hi - lo) == 64) ring_push(&ctl->sec_tail, sa.sec_ring, kb);
+                if (old + (hi - lo) == 64) sec_push(sa, home, kb);
             }
         }
         if (my_total > 0) {
@@ -485,27 +580,20 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
                 if (k <= ((my_base + my_total - 1) >> 6)) {
                     const int lo = my_base > k * 64 ? my_base : k * 64, hi = my_base + my_total < (k + 1) * 64 ? my_base + my_total : (k + 1) * 64;
                     const int old = atomicAdd(sa.sh_fill + lane * bps + k, hi - lo);
-                    if (old + (hi - lo) == 64) ring_push(&ctl->sh_tail, sa.sh_ring, lane * bps + k);
+                    if (old + (hi - lo) == 64) ring_push(&ctl->sh_tail.v, sa.sh_ring, lane * bps + k);
                 }
             }
         }
+        drain();        // the new slots are counted as outstanding before this batch counts itself done
     } else {
         drain();
     }
-    // ---- nodes that are final already (background): their parents hear of it
-    {
-        const bool bg_child = valid && !shaded && g >= sa.n_primary;
-        int par = 0;
-        if (bg_child) par = cldi(sa.parent + g);
-        complete_up(mat, sd, ws, sa, rg.specular, par, bg_child);
-    }
+    // ---- nodes that are final already (background): their parents hear of it (the caller's complete_up)
+    up_active = valid && !shaded && g >= sa.n_primary;
+    if (up_active) up_node = cldi(sa.parent + g);
     // ---- the batch's lighting: later (when its shadow rays are answered), now (it has none), or never (nothing was hit)
-    if (!live) {
-        if (lane == 0) atomicAdd(&ctl->finish_done, 64);
-    } else if (n_sh_batch == 0) {
-        stream_light_batch(blob, mat, sd, ws, rg, sa, nb);
-    }
-    if (lane == 0) atomicAdd(&ctl->nodes_done, 64);
+    any_shaded = live;
+    light_now = live && n_sh_batch == 0;
 }
 
 // ------------------------------------------------------------------ idle wavefronts close the partial batches
@@ -513,7 +601,7 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
 // Reserve the rest of the batch at the end of the node pool / of every shadow segment as padding slots, so that
 // the batch becomes a work item.  Only called by a wavefront that found no work: while there is other work, batches
 // fill up by themselves.  Every lane calls.
-NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
+NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa, int home)
 {
     StreamCtl *ctl = sa.ctl;
     const int lane = __lane_id();
@@ -521,8 +609,8 @@ NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
     {
         int t = 0, won = 0;
         if (lane == 0) {
-            t = cldi(&ctl->node_tail);
-            if ((t & 63) != 0 && t < ws.cap) won = atomicCAS(&ctl->node_tail, t, (t + 63) & ~63) == t;
+            t = cldi(&ctl->node_tail.v);
+            if ((t & 63) != 0 && t < ws.cap) won = atomicCAS(&ctl->node_tail.v, t, (t + 63) & ~63) == t;
         }
         t = __shfl(t, 0, 64);
         won = __shfl(won, 0, 64);
@@ -534,8 +622,9 @@ NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
             }
             drain();
             if (lane == 0) {
+                atomicAdd(&ctl->outstanding[(t >> 6) % NDT_PRIM_SHARDS].v, 2 * pad);
                 const int old = atomicAdd(sa.node_fill + (t >> 6), pad);
-                if (old + pad == 64) ring_push(&ctl->sec_tail, sa.sec_ring, t >> 6);
+                if (old + pad == 64) sec_push(sa, home, t >> 6);
             }
         }
     }
@@ -543,8 +632,8 @@ NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
     {
         int t = 0, won = 0;
         if (lane < sa.n_seg) {
-            t = cldi(&ctl->seg_tail[lane * 16]);
-            if ((t & 63) != 0 && t < sa.seg_cap) won = atomicCAS(&ctl->seg_tail[lane * 16], t, (t + 63) & ~63) == t;
+            t = cldi(&ctl->seg_tail[lane].v);
+            if ((t & 63) != 0 && t < sa.seg_cap) won = atomicCAS(&ctl->seg_tail[lane].v, t, (t + 63) & ~63) == t;
         }
         unsigned long long winners = __ballot(won != 0);
         while (winners) {
@@ -557,7 +646,7 @@ NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
             if (lane == 0) {
                 const int bps = sa.seg_cap >> 6;
                 const int old = atomicAdd(sa.sh_fill + s * bps + (ts >> 6), pad);
-                if (old + pad == 64) ring_push(&ctl->sh_tail, sa.sh_ring, s * bps + (ts >> 6));
+                if (old + pad == 64) ring_push(&ctl->sh_tail.v, sa.sh_ring, s * bps + (ts >> 6));
             }
         }
     }
@@ -565,8 +654,14 @@ NDT_DEV void stream_close_partials(const Workspace &ws, const StreamArgs &sa)
 
 // ------------------------------------------------------------------ the kernel
 
+// 512 lanes per workgroup at most = two wavefronts per SIMD = 256 registers each: with three (768 lanes, 168 registers) the
+// lighting code spilled 800 bytes per lane, 3 072 wavefronts x 51 KB of scratch went through L2 to HBM (0.95 GB written per
+// 1080p frame) and every other memory operation of the kernel queued behind that traffic.
+#ifndef NDT_STREAM_MAX_BLOCK
+#define NDT_STREAM_MAX_BLOCK 512
+#endif
 template <int MW, bool LDS, bool LSTACK = false>
-__global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const double *gblob, SceneDesc sd, Workspace ws, RenderGeom rg,
+__global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const double *gblob, SceneDesc sd, Workspace ws, RenderGeom rg,
                                                                       StreamArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
@@ -596,6 +691,8 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const doub
     VisitMask<MW> mask;
     mask.ext = nullptr;
     mask.ext_stride = 0;
+    mask.live0 = mask.live1 = 0ull;
+    mask.lazy = false;
     if (MW == 0) {
         const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         mask.ext = ws.mask_slab + lane_slot;
@@ -604,21 +701,39 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const doub
     StreamCtl *ctl = sa.ctl;
     const int lane = __lane_id();
     const int n_prim_batches = sa.n_primary >> 6;
-    int shard = blockIdx.x % NDT_PRIM_SHARDS;
+    const int home = blockIdx.x % NDT_PRIM_SHARDS;              // this workgroup's shard of the sharded queues
+    int shard = home;
     unsigned shards_alive = (1u << NDT_PRIM_SHARDS) - 1u;
     const unsigned long long t_begin = wall_clock64();          // 100 MHz
     int idle_rounds = 0;
+    int tk_sec = -1, tk_sec_shard = home;                       // a ticket of a secondary ring whose slot was still empty (sec_pop)
+    // the wavefront's slots in the ring of shadow batches and in the ring of lighting batches (ring_pop): always held
+    int tk_sh = -1, tk_fin = -1;
+    // NDT_HIP_STREAM_PROBE: items and 100 MHz ticks per kind of work, idle rounds, first / last item
+    unsigned int pr_n[4] = { 0, 0, 0, 0 }, pr_t[4] = { 0, 0, 0, 0 }, pr_first = 0, pr_last = 0;
+    unsigned int pr_pop = 0, pr_load = 0, pr_trace = 0;         // of the node and shadow items: looking for work, loading rays, trace_kd
+    unsigned int pr_trace_sh = 0, pr_up = 0;                    // trace_kd of the shadow items alone; complete_up + counters
+    unsigned long long pr_mark = 0, pr_top = 0;
+    WaveStats stats = { 0, 0, 0 };
+    int items = 0;
+    int light_next = -1;            // a node batch this wavefront shaded that has no shadow rays to wait for: lit next
     while (true) {
-        if (cldi(&ctl->abort) != 0) break;
+        // (the abort word is looked at by idle wavefronts and now and then by busy ones)
+        if ((items++ & 15) == 15 && cldi(&ctl->abort.v) != 0) break;
+        if (sa.wave_log) pr_top = wall_clock64();
         // ---- take a work item: deeper rays first (they start the chains everything else waits for), lighting last
         int kind = 0, id = -1;          // 1 node batch, 2 shadow batch, 3 lighting batch
-        if (ring_pop(&ctl->sec_head, &ctl->sec_tail, sa.sec_ring, id, ctl)) {
+        if (light_next >= 0) {
+            kind = 3;
+            id = light_next;
+            light_next = -1;
+        } else if (sec_pop(sa, home, false, tk_sec, tk_sec_shard, id)) {
             kind = 1;
         } else {
             while (shards_alive != 0u && kind == 0) {
                 if ((shards_alive >> shard) & 1u) {
                     int k = 0;
-                    if (lane == 0) k = atomicAdd(&ctl->prim_head[shard * 16], 1);
+                    if (lane == 0) k = atomicAdd(&ctl->prim_head[shard].v, 1);
                     k = __shfl(k, 0, 64);
                     const int b = k * NDT_PRIM_SHARDS + shard;
                     if (b < n_prim_batches) {
@@ -631,10 +746,19 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const doub
                 if (kind == 0) shard = (shard + 1) % NDT_PRIM_SHARDS;
             }
             if (kind == 0) {
-                if (ring_pop(&ctl->sh_head, &ctl->sh_tail, sa.sh_ring, id, ctl)) kind = 2;
-                else if (ring_pop(&ctl->fin_head, &ctl->fin_tail, sa.fin_ring, id, ctl)) kind = 3;
+                if (ring_pop(&ctl->sh_head.v, sa.sh_ring, tk_sh, id)) kind = 2;
+                else if (ring_pop(&ctl->fin_head.v, sa.fin_ring, tk_fin, id)) kind = 3;
+                else if (sec_pop(sa, home, true, tk_sec, tk_sec_shard, id)) kind = 1;       // nothing at home: the other shards
             }
         }
+        if (sa.wave_log && kind != 0) {
+            pr_mark = wall_clock64();
+            if (pr_first == 0) pr_first = (unsigned int)(pr_mark - t_begin) | 1u;
+            pr_pop += (unsigned int)(pr_mark - pr_top);
+        }
+        int up_node = 0;                // what the item leaves to do: nodes whose colour is final report to their parents ...
+        bool up_active = false;
+        int parts_done = 0;             // ... and how many halves (shading, lighting) of batch `id` are complete
         if (kind == 1 || kind == 2) {
             idle_rounds = 0;
             // ---- trace_kd for 64 rays: the nodes of batch `id`, or the shadow rays of batch `id`
@@ -656,7 +780,18 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const doub
                 cload_soa<N>(is_shadow ? ws.so : ws.ray_o, slot, o);
                 cload_soa<N>(is_shadow ? ws.sv : ws.ray_v, slot, v);
                 if (is_shadow) lim = cld(ws.slim + slot);
+                unsigned long long pr_a = 0;
+                if (sa.wave_log) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pr_a = wall_clock64();
+                    pr_load += (unsigned int)(pr_a - pr_mark);
+                }
                 trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+                if (sa.wave_log) {
+                    const unsigned int dt = (unsigned int)(wall_clock64() - pr_a);
+                    pr_trace += dt;
+                    if (is_shadow) pr_trace_sh += dt;
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < N; ++c) { o[c] = 0.0; v[c] = 0.0; }
@@ -679,32 +814,74 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_frame_stream(const doub
                     const unsigned long long span = (end < 64 ? (1ull << end) - 1ull : ~0ull) & ~((1ull << lane) - 1ull);
                     const int run = __popcll(valids & span);
                     const int old = atomicSub(sa.sh_pending + nb, run);
-                    if (old == run) ring_push(&ctl->fin_tail, sa.fin_ring, nb);
+                    if (old == run) ring_push(&ctl->fin_tail.v, sa.fin_ring, nb);
                 }
             } else {
-                stream_shade_batch(blob, gblob, sd, ws, rg, sa, id, valid, tag, o, v, obj, prim);
+                bool light_now, any_shaded;
+                stream_shade_batch(blob, gblob, sd, ws, rg, sa, id, valid, tag, o, v, obj, prim, stats, home, up_node, up_active, light_now,
+                                   any_shaded);
+                parts_done = any_shaded ? 1 : 2;        // nothing hit: no lighting to wait for
+                if (light_now) light_next = id;
             }
         } else if (kind == 3) {
             idle_rounds = 0;
-            stream_light_batch(blob, gblob, sd, ws, rg, sa, id);
-        } else {
-            // ---- nothing to do right now: is the frame done?  (read in this order: a node batch bumps the tail
-            // before it counts itself done, so done == tail means no node batch is in flight or will ever be)
-            const int done = cldi(&ctl->nodes_done);
-            const int tail = cldi(&ctl->node_tail);
-            const int lit = cldi(&ctl->finish_done);
-            if (done == tail && lit == tail) break;
-            stream_close_partials(ws, sa);
+            up_active = stream_light_batch(blob, gblob, sd, ws, rg, sa, id);
+            up_node = id * 64 + lane;
+            parts_done = 1;
+        }
+        if (kind == 1 || kind == 3) {
+            unsigned long long pr_b = 0;
+            if (sa.wave_log) pr_b = wall_clock64();
+            complete_up(gblob, sd, ws, sa, rg.specular, up_node, up_active);
+            if (sa.wave_log) pr_up += (unsigned int)(wall_clock64() - pr_b);
+            if (lane == 0) atomicSub(&ctl->outstanding[id % NDT_PRIM_SHARDS].v, 64 * parts_done);
+        }
+        if (sa.wave_log && kind != 0) {
+            const unsigned long long now = wall_clock64();
+            pr_n[kind] += 1;
+            pr_t[kind] += (unsigned int)(now - pr_mark);
+            pr_last = (unsigned int)(now - t_begin);
+        }
+        if (kind == 0) {
+            pr_n[0] += 1;
+            // ---- nothing to do right now: is the frame done?  Every shard's outstanding count zero, and the node tail the
+            // same before and after reading them (anything that creates work moves the tail first): nothing is in flight and
+            // nothing can appear any more.
+            if (cldi(&ctl->abort.v) != 0) break;
+            const int tail0 = cldi(&ctl->node_tail.v);
+            int left = (lane < NDT_PRIM_SHARDS) ? cldi(&ctl->outstanding[lane].v) : 0;
+            const bool none_left = __ballot(left != 0) == 0ull;
+            if (none_left && cldi(&ctl->node_tail.v) == tail0) break;
+            // every fourth idle round: make work items of the partial batches at the ends of the pools
+            if ((idle_rounds & 3) == 0) stream_close_partials(ws, sa, home);
             ++idle_rounds;
-            if (idle_rounds < 8) __builtin_amdgcn_s_sleep(4);
-            else __builtin_amdgcn_s_sleep(32);
-            if ((idle_rounds & 63) == 0 && wall_clock64() - t_begin > 400000000ull) {     // 4 s: never on a healthy frame
+            if (idle_rounds < 4) __builtin_amdgcn_s_sleep(8);
+            else if (idle_rounds < 16) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(127);
+            if ((idle_rounds & 63) == 0 && wall_clock64() - t_begin > 1000000000ull) {    // 10 s: never on a healthy frame
                 if (lane == 0) {
-                    atomicMax(&ctl->abort, 2);
-                    ctl->timeout_where = 2;
+                    atomicMax(&ctl->abort.v, 2);
+                    ctl->timeout_where.v = 2;
                 }
                 break;
             }
+        }
+    }
+    if (lane == 0) {
+        if (stats.children) atomicAdd(&ctl->n_children.v, stats.children);
+        if (stats.shadow) atomicAdd(&ctl->n_shadow.v, stats.shadow);
+        if (stats.max_level) atomicMax(&ctl->max_level.v, stats.max_level);
+    }
+    if (sa.wave_log && lane == 0) {
+        const unsigned int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+        if (w < NDT_STREAM_LOG_WAVES) {
+            unsigned int *q = sa.wave_log + 24 * w;
+            q[0] = pr_n[1]; q[1] = pr_n[2]; q[2] = pr_n[3]; q[3] = pr_n[0];
+            q[4] = pr_t[1]; q[5] = pr_t[2]; q[6] = pr_t[3];
+            q[7] = pr_first; q[8] = pr_last; q[9] = (unsigned int)(wall_clock64() - t_begin) | 1u;
+            q[10] = (unsigned int)t_begin;
+            q[11] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            q[12] = pr_pop; q[13] = pr_load; q[14] = pr_trace; q[15] = pr_trace_sh; q[16] = pr_up;
         }
     }
 }
@@ -731,8 +908,11 @@ static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd,
     };
     if (tier == 0) {
         const size_t lds = (size_t)sd.trace_words * sizeof(double);
-        int lstack_block = NDT_TRACE_MAX_BLOCK;
+        int lstack_block = NDT_STREAM_MAX_BLOCK;
         if (batches < 4096) lstack_block = 256;         // a small frame is pure latency: one wavefront per SIMD
+#ifdef NDT_STREAM_KNOBS
+        if (getenv("NDT_STREAM_BLOCK")) lstack_block = atoi(getenv("NDT_STREAM_BLOCK"));
+#endif
         const size_t lds_stack = ((size_t)((sd.trace_words + 1) & ~1) * 8) + (size_t)lstack_block * (sd.kd_depth + 1) * 12;
         if (lds_stack <= 160 * 1024 && mask_words <= 1) {
             const int res = resident_blocks(k_frame_stream<1, true, true>, lstack_block, lds_stack);

@@ -270,27 +270,52 @@ def test_stereo_needs_the_eyes(gpu):
         gpu.render(32, 32, 4, stereo=1)
 
 
+def _oracle_ensemble(oracle, g, S, n_seeds):
+    """n_seeds renders of the oracle (= the reference's drand48 stream, restarted from n_seeds different states)."""
+    s0 = g.meta["seed48"]
+    imgs = []
+    for k in range(n_seeds):
+        img, _ = oracle.render(g.scene, g.width, g.height, g.depth, samples=S, seed48=[(s0[0] + 7919 * k) & 0xffff, s0[1], s0[2]])
+        imgs.append(img)
+    return np.array(imgs)
+
+
 @pytest.mark.parametrize("name", SAMPLED_CASES)
 def test_jittered_samples_statistically_match_the_oracle(gpu, oracle, name):
-    """`-n samples` > 1: jitter + lens sampling + adaptive loop.  The reference draws from one global
-    drand48 stream in pixel order (the oracle follows it exactly, test_oracle_golden.py); the device
-    uses its own per-(pixel, sample) streams, so the two are two estimates of the same image: with S
-    samples per pixel the difference behaves like sampling noise, and shrinks when S grows."""
+    """`-n samples` > 1: jitter + lens sampling + adaptive loop (ndt.c:505-567).  The reference draws from one global
+    drand48 stream in pixel order (the oracle follows it exactly, test_oracle_golden.py); the device uses its own
+    per-(pixel, sample) streams, so the device's image is ONE MORE DRAW from the distribution the oracle's images are
+    drawn from.  Tested against an ensemble of 24 oracle renders from different drand48 states: per value,
+    z = (device - ensemble mean) / (ensemble sd * sqrt(1 + 1/24)); the thresholds are what the oracle achieves against
+    its own ensemble (edge pixels are bimodal, so |z| has heavier tails than a normal: 99.6 % below 5 was the worst seen),
+    and a bias of 0.002 in the image mean -- a fifth of what the first version of this test let through -- fails."""
     g = golden(name)
     gpu.upload_scene(g.scene)
     errs = []
+    n_seeds = 24
     for S in (8, 128):
-        want, so = oracle.render(g.scene, g.width, g.height, g.depth, samples=S, seed48=g.meta["seed48"])
+        ens = _oracle_ensemble(oracle, g, S, n_seeds)
         out, st = gpu.render(g.width, g.height, g.depth, samples=S)
         assert st.aa_samples >= S * g.width * g.height          # at least S samples everywhere
         assert st.rays_primary >= st.aa_samples                 # (samples rendered ahead of the loop's exit are dropped)
-        d = np.abs(out[..., :3] - want[..., :3])
-        errs.append(d.mean())
-        assert np.abs(out[..., 3] - want[..., 3]).mean() < 0.05
-        # unbiased: the image means agree much better than single pixels do
-        assert abs(out[..., :3].mean() - want[..., :3].mean()) < 0.01
-    assert errs[1] < 0.6 * errs[0], errs            # noise, not bias: it goes down with more samples
-    assert errs[1] < 0.02, errs
+        mu, sd = ens.mean(axis=0), ens.std(axis=0, ddof=1)
+        noisy = sd > 1e-12
+        # values the sampling cannot move (flat background, alpha of covered pixels): equal outright
+        assert np.abs(out - mu)[~noisy].max() < 1e-9
+        z = (out - mu)[noisy] / (sd[noisy] * np.sqrt(1.0 + 1.0 / n_seeds))
+        frac5 = float((np.abs(z) < 5).mean())
+        print("%s S=%d: %d noisy values, mean z %+.3f, %.2f %% |z|<5, max |z| %.1f" % (name, S, int(noisy.sum()), z.mean(), 100 * frac5, np.abs(z).max()))
+        assert abs(z.mean()) < 0.15, z.mean()
+        assert frac5 > 0.99 and np.abs(z).max() < 15
+        # unbiased: the image mean against the spread of the ensemble's image means
+        means = ens[..., :3].mean(axis=(1, 2, 3))
+        t = (out[..., :3].mean() - means.mean()) / (means.std(ddof=1) * np.sqrt(1.0 + 1.0 / n_seeds))
+        assert abs(t) < 4.5, t
+        assert abs(out[..., :3].mean() - means.mean()) < 0.002
+        errs.append(np.abs(out[..., :3] - mu[..., :3]).mean())
+    # noise, not bias: 16x the samples shrink the error by about sqrt(16) (the adaptive loop takes more than 8 samples
+    # where the colour still moves, so somewhat less: the oracle against its own ensemble gives 0.34)
+    assert 0.15 < errs[1] / errs[0] < 0.5, errs
     # same call, same image; and sharding does not change it
     again, _ = gpu.render(g.width, g.height, g.depth, samples=8)
     first, _ = gpu.render(g.width, g.height, g.depth, samples=8)
