@@ -57,7 +57,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     {
         // which frame pipeline the context uses is fixed here, not looked up on the launch path
         const char *pl = getenv("NDT_HIP_PIPELINE");
-        ctx->use_stream = !(pl && !strcmp(pl, "levels"));
+        ctx->pipeline = !pl ? 0 : !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : 0;
         ctx->stream_probe = getenv("NDT_HIP_STREAM_PROBE") != nullptr;
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

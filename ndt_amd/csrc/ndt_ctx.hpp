@@ -64,7 +64,13 @@ struct ndt_hip_ctx {
     long long ws_slab_words = 0;
     int ws_nseg = 0;
     // the streaming frame kernel (ndt_stream.hpp): its queues and counters live beside the workspace
-    bool use_stream = true;         // false: the bounce-synchronous pipeline (NDT_HIP_PIPELINE=levels at context creation)
+    // Which pipeline renders a pass (fixed at context creation: NDT_HIP_PIPELINE=stream | levels | auto).  auto: the streaming
+    // frame kernel for passes of up to stream_below primaries -- it has no per-bounce latency floor and wins there (64x36:
+    // 0.73 against 0.90 ms, 960x540: 0.89 against 0.98) -- and one trace launch + shade launches per bounce above, where
+    // three wavefronts per SIMD in the trace kernel and massively parallel shade kernels win (1080p 1.62 against 1.87 ms)
+    int pipeline = 0;               // 0 auto, 1 levels, 2 stream
+    long long stream_below = 700000;
+    bool use_stream = false;        // the choice for the pass being rendered
     StreamArgs sa{};
     bool stream_probe = false;      // NDT_HIP_STREAM_PROBE at context creation: profiled frames log what every wavefront did
     long long sa_cap = 0, sa_sh_cap = 0;

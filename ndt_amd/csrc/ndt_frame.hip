@@ -427,6 +427,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     }
 
     const NdtKernelTable *kt = ctx->kt;
+    ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= ctx->stream_below);
     if (ctx->use_stream) {
         // ---- the streaming pipeline: one persistent launch for the whole ray tree (ndt_stream.hpp)
         const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;

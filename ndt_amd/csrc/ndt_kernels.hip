@@ -10,6 +10,11 @@
 //   k_trace        trace_kd for the shadow queue (dist_limit per ray)
 //   k_shade_finish second half of apply_lights (ndt.c:217-310) + the reflect / refract spawn
 //                  of get_ray_color (ndt.c:381-430)                           -> next bounce
+#if NDT_DIMS <= 5 && !defined(NDT_OUTLINE_SMALL)
+// inlined libm and hit-point intersection for the small vectors, out of line for 6-D .. 8-D (ndt_device.hpp, NDT_LIBM)
+#define NDT_INLINE_LIBM 1
+#define NDT_SHADE_INLINE_ISECT 1
+#endif
 #include "ndt_kernels.hpp"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -578,6 +583,49 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
 }
 
 // ------------------------------------------------------------------ shading, first half
+#ifndef NDT_SHADE_WAVES
+// wavefronts per SIMD the lighting kernels are compiled for (256 registers; three -- 168 registers with the intersection out of
+// line -- measured 2-6 % slower on the 3-D and 4-D scenes)
+#define NDT_SHADE_WAVES 2
+#endif
+
+// isect<N, true> as ONE real function for the places of the shading code that re-run a primitive for its hit point
+// and normal (shading: the primitive the traversal returned; lighting: the primitive the shadow ray met).  Inlined, each
+// copy was ~10 KB of code in the middle of a function that already holds four N-vectors: the arguments now travel through
+// the wavefront's private memory (4N doubles per call, twice per node) and the register allocator sees two small
+// functions instead of one that cannot fit.
+struct VecPair {
+    double a[N], b[N];
+};
+#ifndef NDT_SHADE_INLINE_ISECT
+// (arguments and results by value: they travel in registers; by pointer the caller's vectors would live in private memory)
+__device__ __attribute__((noinline)) VecPair isect_full_call(const double *blob, const SceneDesc *sd, int prim, VecPair ray)
+{
+    VecPair out;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { out.a[c] = 0.0; out.b[c] = 0.0; }
+    isect<N, true>(blob, *sd, prim, ray.a, ray.b, out.a, out.b);
+    return out;
+}
+NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
+                        double (&nrm)[N])
+{
+    VecPair ray;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { ray.a[c] = o[c]; ray.b[c] = v[c]; }
+    const VecPair out = isect_full_call(blob, sd, prim, ray);
+#pragma unroll
+    for (int c = 0; c < N; ++c) { hit[c] = out.a[c]; nrm[c] = out.b[c]; }
+}
+#else
+NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
+                        double (&nrm)[N])
+{
+    isect<N, true>(blob, *sd, prim, o, v, hit, nrm);
+}
+#endif
+
+
 
 #ifdef NDT_PHASE_TIMING
 // diagnostic build: wall-clock (100 MHz) stamps of lane 0 of every wavefront, summed per section
@@ -701,7 +749,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             load_soa<N>(ws.ray_v, ws.cap, g, look);
             // the hit point and normal trace_kd would have returned: re-run the one primitive
             // that won the traversal (same arithmetic, same result)
-            isect<N, true>(blob, sd, ws.hit_prim[g], src, look, hit, nrm);
+            isect_full(blob, &sd, ws.hit_prim[g], src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && level == 0) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;    // ndt.c:366-370
@@ -971,7 +1019,7 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
             } else {
                 if (sobj != obj) continue;                  // ndt.c:217
                 double light_hit[N];
-                isect<N, true>(blob, sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                isect_full(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
                 const double dist = v_dist<N>(hit, light_hit);
                 if (dist > NDT_EPS) continue;               // ndt.c:225
             }
@@ -1007,7 +1055,7 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
+__global__ void __launch_bounds__(256, NDT_SHADE_WAVES) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
 {
     const LevelRange lr = ws.levels[level];
     const long long base = (long long)blockIdx.x * blockDim.x;
@@ -1021,7 +1069,7 @@ __global__ void __launch_bounds__(256, 2) k_shade_finish(const double *blob, Sce
 // lighting of bounce `level` in the first n_finish workgroups, shading of bounce level+1 in the rest.  (The other way
 // round -- the long-lived shading wavefronts first -- was measured: they then all contend for the segment counters at
 // once and live 22-32 us instead of 16-19, and the launch takes 20-30 % longer.)
-__global__ void __launch_bounds__(256, 2) k_shade_pair(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
+__global__ void __launch_bounds__(256, NDT_SHADE_WAVES) k_shade_pair(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
                                                        unsigned n_finish)
 {
     __shared__ EmitShared sh;
@@ -1066,7 +1114,7 @@ __global__ void __launch_bounds__(256) k_hitpoints(const double *blob, SceneDesc
     if (p >= 0) {
         load_soa<N>(o, stride, g, ro);
         load_soa<N>(v, stride, g, rv);
-        isect<N, true>(blob, sd, p, ro, rv, h, n);
+        isect_full(blob, &sd, p, ro, rv, h, n);
     }
     store_soa<N>(hit, stride, g, h);
     store_soa<N>(nrm, stride, g, n);

@@ -162,43 +162,6 @@ NDT_DEV bool ring_pop(int *head, const int *ring, int &ticket, int &id)
     return id >= 0;
 }
 
-// ------------------------------------------------------------------ hit point and normal, out of line
-// isect<N, true> as ONE real function for the two places of the frame kernel that re-run a primitive for its hit point
-// and normal (shading: the primitive the traversal returned; lighting: the primitive the shadow ray met).  Inlined, each
-// copy was ~10 KB of code in the middle of a function that already holds four N-vectors: the arguments now travel through
-// the wavefront's private memory (4N doubles per call, twice per node) and the register allocator sees two small
-// functions instead of one that cannot fit.
-struct VecPair {
-    double a[N], b[N];
-};
-#ifndef NDT_STREAM_INLINE_ISECT
-// (arguments and results by value: they travel in registers; by pointer the caller's vectors would live in private memory)
-__device__ __attribute__((noinline)) VecPair isect_full_call(const double *blob, const SceneDesc *sd, int prim, VecPair ray)
-{
-    VecPair out;
-#pragma unroll
-    for (int c = 0; c < N; ++c) { out.a[c] = 0.0; out.b[c] = 0.0; }
-    isect<N, true>(blob, *sd, prim, ray.a, ray.b, out.a, out.b);
-    return out;
-}
-NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
-                        double (&nrm)[N])
-{
-    VecPair ray;
-#pragma unroll
-    for (int c = 0; c < N; ++c) { ray.a[c] = o[c]; ray.b[c] = v[c]; }
-    const VecPair out = isect_full_call(blob, sd, prim, ray);
-#pragma unroll
-    for (int c = 0; c < N; ++c) { hit[c] = out.a[c]; nrm[c] = out.b[c]; }
-}
-#else
-NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
-                        double (&nrm)[N])
-{
-    isect<N, true>(blob, *sd, prim, o, v, hit, nrm);
-}
-#endif
-
 // ------------------------------------------------------------------ the ray tree, bottom-up
 
 // get_ray_color's blend of a node's own colour with what its children returned (ndt.c:402-429): resolve_node of
