@@ -70,15 +70,20 @@ def algorithmic_bytes_per_ray(dims):
     return 64 * dims + 168
 
 
-def pmc_traffic(workload, width, height):
-    """HBM bytes per k_trace launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-    gfx950 correction, calibrated on k_finish_pixels; + WRITE_SIZE) -- profiles/make_traffic_json.py.
-    Counters cannot be read from inside a run, so this is the profile of the same command."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_%s_%dp.json" % (workload, height))
+def committed_profile(workload, width, height):
+    """The committed rocprofv3 session of this very command (profiles/profile_workload.sh -> profiles/make_profile_json.py):
+    HBM bytes per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes (x2 on FETCH_SIZE per the gfx950
+    rule, checked on k_finish_pixels), its FP64-issue figures, and the hash of the library it was measured on.  Counters
+    cannot be read from inside a run; a profile of ANOTHER build is not quoted (traffic stays null, "profile_stale")."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r02_profile_%s_%dp.json" % (workload, height))
     if width != 1920 or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
-        return float(json.load(f)["trace"]["hbm_bytes_per_launch"])
+        prof = json.load(f)
+    lib = os.path.join(ROOT, "ndt_amd", "libndt_hip.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    return prof, prof.get("lib_sha16") == sha
 
 
 def cpu_baseline(workload, width, height, depth, threads=16):
@@ -314,6 +319,48 @@ def main():
         avg_launch_ms = agg["trace_ms"] / max(1, agg["profiled_launches"])
         rays_per_launch = agg["profiled_rays"] / max(1, agg["profiled_launches"])
         achieved = (rays_per_launch * bytes_per_ray) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        ms_per_step = elapsed / steps * 1e3
+        launches_per_step = agg["launches"] / steps
+        stream = launches_per_step <= 1.0 + 1e-9        # the streaming frame kernel: one launch does the whole ray tree
+        prof, fresh = committed_profile(args.workload, width, height) if world == 1 else (None, None)
+        roofline = {
+            # the contract's figure: ALGORITHMIC bytes (64N + 168 per ray, the ray and hit records written and
+            # read once, the framebuffer read-modify-write) of the rays one launch of the dominant kernel traces, over
+            # that kernel's average duration.  The bytes of B_ray are moved by ALL kernels of the frame, the time is one
+            # kernel's: `frac_frame` divides by the whole frame instead, and `measured` is what the counters saw.
+            "bound": "hbm",
+            "kernel": "k_frame_stream (the whole ray tree in one persistent launch)" if stream else "k_trace (trace_kd, one ray per lane)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_frame": (total_traced / steps / max(1, world)) * bytes_per_ray / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": prof["hbm_bytes_per_launch"] if (prof and fresh and "hbm_bytes_per_launch" in prof) else None,
+            "traffic_unit": "HBM bytes per launch of that kernel: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of this "
+                            "command (profiles/profile_workload.sh), quoted only when measured on this very libndt_hip.so",
+            "profile_stale": (None if prof is None else (not fresh)),
+            "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
+            "bytes_per_ray": bytes_per_ray,
+            "kernel_own_bytes_per_ray": 16 * dims + 16,     # what the trace kernel itself must move: o, v, dist_limit in; object, primitive out
+            "rays_per_launch": rays_per_launch,
+            "avg_launch_ms": avg_launch_ms,
+            "launches_per_step": launches_per_step,
+            "profiled_steps": agg["profiled_steps"],
+            "timing": "HIP events on the renderer's stream carrying the kernels' own dispatch timestamps, on every "
+                      "%s timed step" % ("" if every == 1 else "%d-th" % every),
+        }
+        if prof and fresh:
+            if "hbm_bytes_per_launch" in prof:
+                gbs = prof["hbm_bytes_per_launch"] / (prof["avg_launch_ns"] * 1e-9) / 1e9
+                roofline["measured"] = {"hbm_gbs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                        "bytes_per_ray": prof["hbm_bytes_per_launch"] / max(1.0, rays_per_launch),
+                                        "avg_launch_ms_under_rocprof": prof["avg_launch_ns"] * 1e-6}
+            if "fp64_valu_issue_frac" in prof:
+                # the bound that actually holds: FP64 vector issue and the latency of a divergent traversal
+                roofline["secondary"] = {"bound": "fp64_valu_issue", "frac": prof["fp64_valu_issue_frac"],
+                                         "lane_util": prof.get("lane_utilisation"), "salu_per_valu": prof.get("salu_per_valu"),
+                                         "wait_frac_of_wave_cycles": prof.get("wait_frac_of_wave_cycles"),
+                                         "source": "profiles/r02_profile_%s_%dp.json" % (args.workload, height)}
         line = {
             "metric": "Mray/s (primary+shadow+reflect) at 1920x1080",
             "value": total_traced / elapsed / 1e6,
@@ -321,7 +368,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -342,24 +389,7 @@ def main():
             "ray_mix_rank0_per_step": {"primary": agg["primary"] / steps, "secondary": agg["secondary"] / steps,
                                         "shadow": agg["shadow"] / steps, "bounces": agg["levels"]},
             "device_frame_ms_rank0": agg["frame_ms"] / max(1, agg["profiled_steps"]),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_trace (trace_kd, one ray per lane)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload, width, height) if world == 1 else None,
-                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_traffic_*.json)",
-                "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
-                "bytes_per_ray": bytes_per_ray,
-                "rays_per_launch": rays_per_launch,
-                "avg_launch_ms": avg_launch_ms,
-                "launches_per_step": agg["launches"] / steps,
-                "profiled_steps": agg["profiled_steps"],
-                "timing": "HIP events on the renderer's stream carrying the trace kernels' dispatch timestamps, on every "
-                          "%s timed step" % ("" if every == 1 else "%d-th" % every),
-            },
+            "roofline": roofline,
         }
         if world == 1:
             # what a caller of ndt_hip_render_rgba8 waits for: render + pixel_d2c on the device + the 4-bytes-per-pixel
