@@ -57,7 +57,8 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     {
         // which frame pipeline the context uses is fixed here, not looked up on the launch path
         const char *pl = getenv("NDT_HIP_PIPELINE");
-        ctx->pipeline = !pl ? 0 : !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : 0;
+        ctx->pipeline = !pl ? 0 : !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0;
+        if (getenv("NDT_HIP_HYBRID_LEVEL")) ctx->hybrid_level = atoi(getenv("NDT_HIP_HYBRID_LEVEL"));
         ctx->stream_probe = getenv("NDT_HIP_STREAM_PROBE") != nullptr;
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -72,9 +73,9 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail, ctx->h_mail, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_mail_tag, ctx->h_mail_tag, 0);
     if (e == hipSuccess) memset(ctx->h_mail_tag, 0, (NDT_MAX_LEVELS + 2) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_done, 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_done, 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->d_done, ctx->h_done, 0);
-    if (e == hipSuccess) memset(ctx->h_done, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) memset(ctx->h_done, 0, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;

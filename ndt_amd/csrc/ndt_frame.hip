@@ -140,7 +140,9 @@ __global__ void k_frame_init(Workspace ws, int n_primary, LevelRange level0, int
 // tag instead of queueing three small read-backs and synchronising the stream.  One wavefront.
 //   [0] node tail  [1] overflow flags  [2] shadow slots wanted  [3] shadow rays of the frame  [4] bounces with nodes
 //   [5] rays the reference would have traced  [7] tag
-__global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, unsigned long long tag)
+// Hybrid pipeline (`c` set): the frame kernel rendered the deeper bounces; its counts are added and its flags reported:
+//   [8] its overflow flags  [9] its abort word  [10] nodes it spawned
+__global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, unsigned long long tag, const StreamCtl *c)
 {
     const int lane = threadIdx.x;
     unsigned long long ref = ws.ref_rays[8 * lane];         // 64 partial sums, one 64-byte line each
@@ -156,6 +158,14 @@ __global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, 
     done[0] = (unsigned long long)(long long)ws.counters[0];
     done[1] = (unsigned long long)(long long)ws.counters[2];
     done[2] = (unsigned long long)(long long)ws.counters[3];
+    done[8] = done[9] = done[10] = 0ull;
+    if (c) {
+        shadow += c->n_shadow.v;
+        if (c->max_level.v + 1 > used) used = c->max_level.v + 1;
+        done[8] = (unsigned long long)(long long)c->overflow.v;
+        done[9] = (unsigned long long)(long long)(c->abort.v | (c->timeout_where.v << 8));
+        done[10] = (unsigned long long)(long long)c->n_children.v;
+    }
     done[3] = (unsigned long long)shadow;
     done[4] = (unsigned long long)used;
     done[5] = ref;
@@ -165,19 +175,23 @@ __global__ void k_frame_done(Workspace ws, int n_run, unsigned long long *done, 
 
 // The streaming pipeline's frame reset: control block, fill / lighting counters and rings of the batches the frame can
 // have, the reference-ray partial sums.  (Sized by the pool, not by the frame: a few MB of zeros.)
-__global__ void __launch_bounds__(256) k_stream_init(Workspace ws, StreamArgs sa, long long node_batches, long long sh_batches)
+// (frame_too: also the frame's own accumulators -- not in the hybrid pipeline, where the per-bounce kernels own them)
+__global__ void __launch_bounds__(256) k_stream_init(Workspace ws, StreamArgs sa, long long node_batches, long long sh_batches, int frame_too)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     // the control block: zeros, except the node tail (the pool behind the primaries is free) and the primaries' share of
     // every shard's outstanding count -- written by the thread that owns the word, so that no zero can land on top of it
     int *ctl = reinterpret_cast<int *>(sa.ctl);
-    const int prim_batches = sa.n_primary >> 6;
+    const int nb0 = sa.root_begin >> 6, nb1 = nb0 + (sa.n_primary >> 6);       // the root batches
     for (long long k = i; k < (long long)(sizeof(StreamCtl) / sizeof(int)); k += stride) {
         int v = 0;
-        if (k == (long long)(offsetof(StreamCtl, node_tail) / sizeof(int))) v = sa.n_primary;
+        if (k == (long long)(offsetof(StreamCtl, node_tail) / sizeof(int))) v = sa.root_begin + sa.n_primary;
         for (int sh = 0; sh < NDT_PRIM_SHARDS; ++sh)
-            if (k == (long long)((offsetof(StreamCtl, outstanding) + sh * sizeof(StreamWord)) / sizeof(int)))
-                v = 128 * ((prim_batches + NDT_PRIM_SHARDS - 1 - sh) / NDT_PRIM_SHARDS);
+            if (k == (long long)((offsetof(StreamCtl, outstanding) + sh * sizeof(StreamWord)) / sizeof(int))) {
+                // root batches nb in [nb0, nb1) with nb % 8 == sh
+                const int first = nb0 + ((sh - nb0 % NDT_PRIM_SHARDS) + NDT_PRIM_SHARDS) % NDT_PRIM_SHARDS;
+                v = first < nb1 ? 128 * ((nb1 - 1 - first) / NDT_PRIM_SHARDS + 1) : 0;
+            }
         ctl[k] = v;
     }
     for (long long k = i; k < node_batches; k += stride) {
@@ -190,8 +204,10 @@ __global__ void __launch_bounds__(256) k_stream_init(Workspace ws, StreamArgs sa
         sa.sh_fill[k] = 0;
         sa.sh_ring[k] = 0;
     }
-    for (long long k = i; k < 64 * 8; k += stride) ws.ref_rays[k] = 0ull;
-    for (long long k = i; k < 4; k += stride) ws.counters[k] = 0;
+    if (frame_too) {
+        for (long long k = i; k < 64 * 8; k += stride) ws.ref_rays[k] = 0ull;
+        for (long long k = i; k < 4; k += stride) ws.counters[k] = 0;
+    }
 }
 
 // The streaming pipeline's closing record, in host-visible memory (the host polls the tag):
@@ -390,116 +406,9 @@ void ndt_impl::add_stats(ndt_render_stats &acc, const ndt_render_stats &st)
 
 // ------------------------------------------------------------------ render
 
-static hipEvent_t get_event(ndt_hip_ctx *ctx, size_t idx)
+// NDT_HIP_STREAM_PROBE: what every wavefront of the frame kernel did and when (100 MHz ticks)
+static void print_stream_probe(const unsigned int *wave_log, float km)
 {
-    while (ctx->ev_pool.size() <= idx) {
-        hipEvent_t ev;
-        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-        ctx->ev_pool.push_back(ev);
-    }
-    return ctx->ev_pool[idx];
-}
-
-static double wall_s()
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
-// One pass of the ray pipeline over the primaries `rg` describes: primary rays, the bounce loop,
-// bottom-up resolve, per-primary colour (k_finish_pixels) into d_rgba.  Grid mode writes a
-// rows x width image, list mode one RGBA per sample.  max_depth > 0 (the callers handle -l 0).
-int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth)
-{
-    rg.want_depth = d_depth ? 1 : 0;
-    hipStream_t s = ctx->stream;
-    const long long n_primary = rg.n_primary;
-    const long long n_pixels = rg.samples ? (long long)rg.n_samples : (long long)rg.rows * rg.width;
-    long long cap = ctx->ws.cap, sh_cap = ctx->ws.sh_cap;
-    if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
-    const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
-    if (sh_cap < want_sh) sh_cap = want_sh;
-    if (getenv("NDT_HIP_TEST_SMALL_POOL") && ctx->ws.cap == 0) {
-        // tests only: a fresh context starts with a node pool that a reflective scene overflows, so that the
-        // overflow -> grow -> render-again path below is exercised (tests/test_gpu_parity.py)
-        cap = ((n_primary + 63) & ~63LL) + 64;
-    }
-
-    const NdtKernelTable *kt = ctx->kt;
-    ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= ctx->stream_below);
-    if (ctx->use_stream) {
-        // ---- the streaming pipeline: one persistent launch for the whole ray tree (ndt_stream.hpp)
-        const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
-        for (int attempt = 0; attempt < 8; ++attempt) {
-            // every light's shadow segment can hold one ray per node
-            if (sh_cap < cap * n_seg) sh_cap = cap * n_seg;
-            if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
-            int rc = ensure_workspace(ctx, cap, sh_cap);
-            if (rc) return rc;
-            if ((rc = ensure_stream_args(ctx))) return rc;
-            Workspace ws = ctx->ws;
-            StreamArgs sa = ctx->sa;
-            sa.n_primary = rg.n_primary;
-            unsigned int *wave_log = sa.wave_log;
-            if (!prof) sa.wave_log = nullptr;
-            else if (wave_log) HIP_TRY(hipMemsetAsync(wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
-            hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
-            if (prof) {
-                ev_begin = get_event(ctx, 0);
-                ev_end = get_event(ctx, 1);
-                ev_k0 = get_event(ctx, 2);
-                ev_k1 = get_event(ctx, 3);
-            }
-            const unsigned long long tag = ++ctx->frame_tag;
-            const long long node_batches = sa.node_batches, sh_batches = (long long)sa.n_seg * (sa.seg_cap / 64) + NDT_STREAM_LOG_WAVES;
-            if (prof)
-                hipExtLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, sa, node_batches, sh_batches);
-            else
-                hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, node_batches, sh_batches);
-            kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
-            kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
-            hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
-                               rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
-            if (prof)
-                hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
-            else
-                hipLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, ws, sa, ctx->d_done, tag);
-            HIP_TRY(hipGetLastError());
-            {
-                const double t_wait = wall_s();
-                while (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) {
-                    if (wall_s() - t_wait > 30.0) {
-                        HIP_TRY(hipStreamSynchronize(s));
-                        if (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "the frame never completed");
-                    }
-                }
-            }
-            if (prof) HIP_TRY(hipEventSynchronize(ev_end));
-            const int overflow = (int)(long long)ctx->h_done[1], aborted = (int)(long long)ctx->h_done[2];
-            if (overflow != 0) {
-                if (overflow & 1) cap *= 2;
-                if (overflow & 2) sh_cap *= 2;
-                continue;
-            }
-            if (aborted != 0)
-                return fail(NDT_E_STATE, "the frame kernel gave up (abort %d, where %d): a work item never arrived", aborted & 0xff, aborted >> 8);
-            st = ndt_render_stats{};
-            st.rays_primary = n_pixels;
-            st.rays_secondary = (long long)ctx->h_done[6];
-            st.rays_shadow = (long long)ctx->h_done[3];
-            st.rays_ref_equiv = (long long)ctx->h_done[5];
-            st.levels = (int)ctx->h_done[4];
-            st.trace_launches = 1;
-            st.node_capacity = ws.cap;
-            if (prof) {
-                float km = 0, fm = 0;
-                HIP_TRY(hipEventElapsedTime(&km, ev_k0, ev_k1));
-                HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
-                st.trace_ms = km;
-                st.frame_ms = fm;
-                if (wave_log) {
-                    // NDT_HIP_STREAM_PROBE: what every wavefront of the frame kernel did and when (100 MHz ticks)
                     std::vector<unsigned int> log((size_t)24 * NDT_STREAM_LOG_WAVES);
                     if (hipMemcpy(log.data(), wave_log, log.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
                         unsigned long long n[4] = { 0, 0, 0, 0 }, t[3] = { 0, 0, 0 }, parts[5] = { 0, 0, 0, 0, 0 };
@@ -551,7 +460,123 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                                 (n[0] + n[1]) ? parts[1] / 100.0 / (n[0] + n[1]) : 0.0, n[0] ? (parts[2] - parts[3]) / 100.0 / n[0] : 0.0,
                                 n[1] ? parts[3] / 100.0 / n[1] : 0.0, (n[0] + n[2]) ? parts[4] / 100.0 / (n[0] + n[2]) : 0.0);
                     }
+}
+
+
+static hipEvent_t get_event(ndt_hip_ctx *ctx, size_t idx)
+{
+    while (ctx->ev_pool.size() <= idx) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(ev);
+    }
+    return ctx->ev_pool[idx];
+}
+
+static double wall_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// One pass of the ray pipeline over the primaries `rg` describes: primary rays, the bounce loop,
+// bottom-up resolve, per-primary colour (k_finish_pixels) into d_rgba.  Grid mode writes a
+// rows x width image, list mode one RGBA per sample.  max_depth > 0 (the callers handle -l 0).
+int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth)
+{
+    rg.want_depth = d_depth ? 1 : 0;
+    hipStream_t s = ctx->stream;
+    const long long n_primary = rg.n_primary;
+    const long long n_pixels = rg.samples ? (long long)rg.n_samples : (long long)rg.rows * rg.width;
+    long long cap = ctx->ws.cap, sh_cap = ctx->ws.sh_cap;
+    if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
+    const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
+    if (sh_cap < want_sh) sh_cap = want_sh;
+    if (getenv("NDT_HIP_TEST_SMALL_POOL") && ctx->ws.cap == 0) {
+        // tests only: a fresh context starts with a node pool that a reflective scene overflows, so that the
+        // overflow -> grow -> render-again path below is exercised (tests/test_gpu_parity.py)
+        cap = ((n_primary + 63) & ~63LL) + 64;
+    }
+
+    const NdtKernelTable *kt = ctx->kt;
+    ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= ctx->stream_below);
+    const bool hybrid = !ctx->use_stream && ctx->pipeline == 3 && ctx->hybrid_level >= 1 && rg.max_depth > ctx->hybrid_level;
+    if (ctx->use_stream) {
+        // ---- the streaming pipeline: one persistent launch for the whole ray tree (ndt_stream.hpp)
+        const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            // every light's shadow segment can hold one ray per node
+            if (sh_cap < cap * n_seg) sh_cap = cap * n_seg;
+            if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
+            int rc = ensure_workspace(ctx, cap, sh_cap);
+            if (rc) return rc;
+            if ((rc = ensure_stream_args(ctx))) return rc;
+            Workspace ws = ctx->ws;
+            StreamArgs sa = ctx->sa;
+            sa.root_begin = 0;
+            sa.n_primary = rg.n_primary;
+            sa.roots_are_primaries = 1;
+            sa.valid_begin = 0;
+            sa.valid_end = rg.n_primary;
+            unsigned int *wave_log = sa.wave_log;
+            if (!prof) sa.wave_log = nullptr;
+            else if (wave_log) HIP_TRY(hipMemsetAsync(wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
+            hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+            if (prof) {
+                ev_begin = get_event(ctx, 0);
+                ev_end = get_event(ctx, 1);
+                ev_k0 = get_event(ctx, 2);
+                ev_k1 = get_event(ctx, 3);
+            }
+            const unsigned long long tag = ++ctx->frame_tag;
+            const long long node_batches = sa.node_batches, sh_batches = (long long)sa.n_seg * (sa.seg_cap / 64) + NDT_STREAM_LOG_WAVES;
+            if (prof)
+                hipExtLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, sa, node_batches, sh_batches, 1);
+            else
+                hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, node_batches, sh_batches, 1);
+            kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+            kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
+            hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                               rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+            if (prof)
+                hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
+            else
+                hipLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, ws, sa, ctx->d_done, tag);
+            HIP_TRY(hipGetLastError());
+            {
+                const double t_wait = wall_s();
+                while (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) {
+                    if (wall_s() - t_wait > 30.0) {
+                        HIP_TRY(hipStreamSynchronize(s));
+                        if (__atomic_load_n(&ctx->h_done[7], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "the frame never completed");
+                    }
                 }
+            }
+            if (prof) HIP_TRY(hipEventSynchronize(ev_end));
+            const int overflow = (int)(long long)ctx->h_done[1], aborted = (int)(long long)ctx->h_done[2];
+            if (overflow != 0) {
+                if (overflow & 1) cap *= 2;
+                if (overflow & 2) sh_cap *= 2;
+                continue;
+            }
+            if (aborted != 0)
+                return fail(NDT_E_STATE, "the frame kernel gave up (abort %d, where %d): a work item never arrived", aborted & 0xff, aborted >> 8);
+            st = ndt_render_stats{};
+            st.rays_primary = n_pixels;
+            st.rays_secondary = (long long)ctx->h_done[6];
+            st.rays_shadow = (long long)ctx->h_done[3];
+            st.rays_ref_equiv = (long long)ctx->h_done[5];
+            st.levels = (int)ctx->h_done[4];
+            st.trace_launches = 1;
+            st.node_capacity = ws.cap;
+            if (prof) {
+                float km = 0, fm = 0;
+                HIP_TRY(hipEventElapsedTime(&km, ev_k0, ev_k1));
+                HIP_TRY(hipEventElapsedTime(&fm, ev_begin, ev_end));
+                st.trace_ms = km;
+                st.frame_ms = fm;
+                if (wave_log) print_stream_probe(wave_log, km);
             }
             return NDT_OK;
         }
@@ -561,6 +586,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
         int rc = ensure_workspace(ctx, cap, sh_cap);
         if (rc) return rc;
+        if (hybrid && (rc = ensure_stream_args(ctx))) return rc;
         Workspace ws = ctx->ws;
         size_t ev_n = 0;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -648,7 +674,14 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         static const bool fuse_shade = !(getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR")));
         int pending_finish = -1;                // bounce whose lighting has not been launched yet
         long long pending_upper = 0;
-        for (int b = 0; b < n_levels; ++b) {
+        // Hybrid pipeline: the first `hand` bounces -- where the rays are -- go through the per-bounce kernels (three
+        // wavefronts per SIMD in the trace kernel, shade kernels with the whole chip's wavefront slots); the deeper
+        // bounces, a few per cent of the rays but a launch latency each (one slow batch: 0.15-0.2 ms per trace launch
+        // and 75 us per shade launch, three times over on the benchmark frame), are ONE launch of the frame kernel
+        // rooted at the nodes of bounce `hand`.
+        const int hand = hybrid ? ctx->hybrid_level : n_levels + 1;
+        bool streamed = false;
+        for (int b = 0; b < n_levels && b < hand; ++b) {
             if (queue_slot + 1 > NDT_QUEUE_SLOTS || b + 1 > NDT_MAX_LEVELS)
                 return fail(NDT_E_UNSUPPORTED, "more than %d bounces", NDT_QUEUE_SLOTS - 1);
             if (b > 0) {
@@ -694,13 +727,55 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
                 tj.begin = 0;
                 tj.count = next_upper;                          // sizes the grid only
-                tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = b + 1;
-                if ((rc = traced(tj, "shadow " + std::to_string(b) + " + closest " + std::to_string(b + 1)))) return rc;
+                tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = (b + 1 == hand) ? -1 : b + 1;     // the frame kernel traces bounce `hand`
+                if ((rc = traced(tj, "shadow " + std::to_string(b) + (b + 1 == hand ? "" : " + closest " + std::to_string(b + 1))))) return rc;
             }
             pending_finish = b;
             pending_upper = upper;
         }
         if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+        StreamArgs sa = ctx->sa;
+        hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+        if (hybrid && n_run >= hand && hand < n_levels) {
+            // the nodes of bounce `hand`: posted by k_level_step(hand - 1)
+            const double t_wait = wall_s();
+            while (__atomic_load_n(&ctx->h_mail_tag[hand], __ATOMIC_ACQUIRE) != tag) {
+                if (wall_s() - t_wait > 30.0) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (__atomic_load_n(&ctx->h_mail_tag[hand], __ATOMIC_ACQUIRE) != tag) return fail(NDT_E_STATE, "bounce %d was never published", hand);
+                }
+            }
+            const LevelRange roots = ctx->h_mail[hand];
+            if (roots.count > 0) {
+                // the root range = the 64-aligned cover of the bounce's node range (the frame kernel works in batches of
+                // 64 slots); its queues are reset, and it runs
+                sa.root_begin = (int)(roots.begin & ~63LL);
+                sa.n_primary = (int)(((roots.begin + roots.count + 63) & ~63LL) - sa.root_begin);
+                sa.valid_begin = (int)roots.begin;
+                sa.valid_end = (int)(roots.begin + roots.count);
+                sa.roots_are_primaries = 0;
+                if (!prof) sa.wave_log = nullptr;
+                else if (sa.wave_log) HIP_TRY(hipMemsetAsync(sa.wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
+                if ((long long)sa.root_begin + sa.n_primary > ws.cap) {
+                    cap *= 2;
+                    continue;
+                }
+                const long long sh_batches = (long long)sa.n_seg * (sa.seg_cap / 64) + NDT_STREAM_LOG_WAVES;
+                hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, (long long)sa.node_batches, sh_batches, 0);
+                if (prof) {
+                    ev_k0 = get_event(ctx, ev_n++);
+                    ev_k1 = get_event(ctx, ev_n++);
+                }
+                kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
+                if (prof) {
+                    trace_ev.push_back({ ev_k0, ev_k1 });
+                    trace_dbg.push_back("frame kernel, bounces " + std::to_string(hand) + " ..");
+                }
+                ++launches;
+                streamed = true;
+            }
+            n_run = hand;           // the bounces the per-bounce resolve below walks
+        }
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
             for (int b = n_run; b-- > 0;) {
@@ -711,10 +786,11 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
                            rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+        const StreamCtl *sctl = streamed ? sa.ctl : nullptr;
         if (prof)
-            hipExtLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, n_run, ctx->d_done, tag);
+            hipExtLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, n_run, ctx->d_done, tag, sctl);
         else
-            hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag);
+            hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag, sctl);
         HIP_TRY(hipGetLastError());
         if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
             // the bounce table only feeds the debug output
@@ -736,20 +812,28 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         hc[2] = (int)(long long)ctx->h_done[1];
         hc[3] = (int)(long long)ctx->h_done[2];
         const unsigned long long ref_rays = ctx->h_done[5];
-        if (hc[2] != 0) {
+        const int s_overflow = (int)(long long)ctx->h_done[8], s_abort = (int)(long long)ctx->h_done[9];
+        if (hc[2] != 0 || s_overflow != 0) {
+            if (getenv("NDT_HIP_DEBUG_LEVELS"))
+                fprintf(stderr, "ndt_hip: overflow: per-bounce kernels %d (needs %d), frame kernel %d; pool %lld nodes, %lld shadow slots\n", hc[2],
+                        hc[3], s_overflow, cap, sh_cap);
             // a pool overflowed somewhere in the frame: grow it and render again
-            if (hc[2] & 1) cap *= 2;
-            if (hc[2] & 2) {
+            if ((hc[2] & 1) || (s_overflow & 1)) cap *= 2;
+            if ((hc[2] & 2) || (s_overflow & 2)) {
                 sh_cap *= 2;
                 if (sh_cap < hc[3]) sh_cap = hc[3];
             }
+            // (the frame kernel keeps the shadow rays of ALL its bounces: its segments grow with the node pool, together)
+            if (s_overflow != 0 && sh_cap < cap * (n_seg > 0 ? n_seg : 1)) sh_cap = cap * (n_seg > 0 ? n_seg : 1);
             continue;
         }
+        if (s_abort != 0)
+            return fail(NDT_E_STATE, "the frame kernel gave up (abort %d, where %d): a work item never arrived", s_abort & 0xff, s_abort >> 8);
         const long long shadow_total = (long long)ctx->h_done[3];
         const int levels_used = (int)ctx->h_done[4];
         st = ndt_render_stats{};
         st.rays_primary = n_pixels;
-        st.rays_secondary = (long long)hc[0] - rg.n_primary;
+        st.rays_secondary = (long long)hc[0] - rg.n_primary + (long long)ctx->h_done[10];
         st.rays_shadow = shadow_total;
         st.rays_ref_equiv = (long long)ref_rays;
         st.levels = levels_used;
@@ -763,6 +847,11 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 ms += m;
             }
             st.trace_ms = ms;
+            if (streamed && sa.wave_log && ev_k0) {
+                float km = 0;
+                HIP_TRY(hipEventElapsedTime(&km, ev_k0, ev_k1));
+                print_stream_probe(sa.wave_log, km);
+            }
             if (getenv("NDT_HIP_DEBUG_LEVELS")) {
                 for (int b = 0; b < levels_used; ++b)
                     fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);

@@ -305,8 +305,12 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
     long long dense_count = job.count, dense_begin = job.begin, seg_stride = job.seg_stride;
     if (job.levels) {
         // ranges produced earlier on this stream (k_level_step)
-        dense_begin = job.levels[job.dense_level].begin;
-        dense_count = job.levels[job.dense_level].count;
+        if (job.dense_level >= 0) {
+            dense_begin = job.levels[job.dense_level].begin;
+            dense_count = job.levels[job.dense_level].count;
+        } else {
+            dense_count = 0;        // shadow rays only (the next bounce's nodes go to the frame kernel: hybrid pipeline)
+        }
         seg_stride = job.levels[job.seg_level].seg_stride;
     }
     const long long dense_batches = (dense_count + bs - 1) >> sh;

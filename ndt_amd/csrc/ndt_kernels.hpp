@@ -160,7 +160,15 @@ struct StreamArgs {
     int *sowner;            // [n_seg * seg_cap]  the node a shadow ray belongs to, -1 = padding slot
     int n_seg;
     int seg_cap;            // slots per light segment (multiple of 64)
-    int n_primary;          // multiple of 64
+    // The roots of the forest the launch renders: node slots [root_begin, root_begin + n_primary), both multiples of 64.  A
+    // whole frame: the primaries (root_begin = 0).  The deep bounces of a frame whose first bounces went through the
+    // per-bounce kernels: the nodes of the first bounce the frame kernel takes over (render_pass, hybrid pipeline).
+    int root_begin;
+    int n_primary;
+    int roots_are_primaries;    // 1: the roots are the frame's primary rays (depth maps record their hits)
+    // of the root batches' slots only [valid_begin, valid_end) are roots (the first and the last root batch may hold slots
+    // of the bounce before / slots nobody has written: the root range is the 64-aligned cover of a bounce's node range)
+    int valid_begin, valid_end;
     int node_batches;       // cap / 64: entries per shard of sec_ring
     unsigned int *wave_log; // NDT_HIP_STREAM_PROBE: 16 words per wavefront (what it did and when), else nullptr
 };

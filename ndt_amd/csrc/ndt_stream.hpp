@@ -215,8 +215,8 @@ NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace
                 active = false;
             } else {
                 stream_resolve(mat, sd, ws, specular, cur);
-                if (cur < sa.n_primary) {
-                    active = false;                 // a primary: k_finish_pixels takes it from here
+                if (cur < sa.root_begin + sa.n_primary) {
+                    active = false;                 // a root of the forest (a primary: k_finish_pixels takes it from here)
                 } else {
                     cur = cldi(sa.parent + cur);
                 }
@@ -235,7 +235,8 @@ NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const Sce
 {
     const long long g = (long long)nb * 64 + __lane_id();
     int obj = -1;
-    if (cldi(ws.depth_left + g) > 0) obj = cldi(ws.hit_obj + g);
+    const bool ours = g >= sa.root_begin + sa.n_primary || (g >= sa.valid_begin && g < sa.valid_end);
+    if (ours && cldi(ws.depth_left + g) > 0) obj = cldi(ws.hit_obj + g);
     const bool shaded = obj >= 0;
     if (shaded) {
         double src[N], look[N], nrm[N], hit[N];
@@ -353,8 +354,8 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
             isect_full(blob, &sd, prim, src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
-            if (rg.want_depth && g < sa.n_primary) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;     // ndt.c:366-370
-        } else if (rg.want_depth && g < sa.n_primary) {
+            if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;     // ndt.c:366-370
+        } else if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) {
             ws.depth[g] = 0.0;                                              // ndt.c:372-373
         }
         if (shaded) {
@@ -552,7 +553,7 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
         drain();
     }
     // ---- nodes that are final already (background): their parents hear of it (the caller's complete_up)
-    up_active = valid && !shaded && g >= sa.n_primary;
+    up_active = valid && !shaded && g >= sa.root_begin + sa.n_primary;
     if (up_active) up_node = cldi(sa.parent + g);
     // ---- the batch's lighting: later (when its shadow rays are answered), now (it has none), or never (nothing was hit)
     any_shaded = live;
@@ -661,6 +662,14 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
         mask.ext = ws.mask_slab + lane_slot;
         mask.ext_stride = (int)ws.mask_slab_lanes;
     }
+    // Idle wavefronts: ONE per workgroup (the first: the watcher) looks at the frame's global words -- is everything done, are
+    // there partial batches to close -- and tells the others through LDS.  With every idle wavefront doing that (a dozen
+    // agent-scope loads of the same few words per round) a launch with more wavefronts than work spent its time in the queue
+    // of those words' memory channels: the deep bounces of the benchmark frame, 0.6 M rays, took 1.3 ms.
+    __shared__ int wg_over;
+    if (threadIdx.x == 0) wg_over = 0;
+    __syncthreads();
+    const bool watcher = threadIdx.x < 64;
     StreamCtl *ctl = sa.ctl;
     const int lane = __lane_id();
     const int n_prim_batches = sa.n_primary >> 6;
@@ -701,7 +710,7 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                     const int b = k * NDT_PRIM_SHARDS + shard;
                     if (b < n_prim_batches) {
                         kind = 1;
-                        id = b;
+                        id = (sa.root_begin >> 6) + b;
                     } else {
                         shards_alive &= ~(1u << shard);
                     }
@@ -711,7 +720,8 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
             if (kind == 0) {
                 if (ring_pop(&ctl->sh_head.v, sa.sh_ring, tk_sh, id)) kind = 2;
                 else if (ring_pop(&ctl->fin_head.v, sa.fin_ring, tk_fin, id)) kind = 3;
-                else if (sec_pop(sa, home, true, tk_sec, tk_sec_shard, id)) kind = 1;       // nothing at home: the other shards
+                else if ((watcher || (idle_rounds & 3) == 3) && sec_pop(sa, home, true, tk_sec, tk_sec_shard, id))
+                    kind = 1;       // nothing at home: the other shards (eight words: not every wavefront every round)
             }
         }
         if (sa.wave_log && kind != 0) {
@@ -735,7 +745,9 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                 slot = (long long)id * 64 + lane;
             }
             const int tag = is_shadow ? cldi(sa.sowner + slot) : cldi(ws.depth_left + slot);     // owner node / bounces left
-            const bool valid = is_shadow ? tag >= 0 : tag > 0;
+            // (a slot of a root batch outside the roots' range is not this launch's node)
+            const bool valid = is_shadow ? tag >= 0
+                                         : tag > 0 && (slot >= sa.root_begin + sa.n_primary || (slot >= sa.valid_begin && slot < sa.valid_end));
             double o[N], v[N];
             double lim = -1.0;
             int obj = -1, prim = -1;
@@ -810,13 +822,22 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
             // ---- nothing to do right now: is the frame done?  Every shard's outstanding count zero, and the node tail the
             // same before and after reading them (anything that creates work moves the tail first): nothing is in flight and
             // nothing can appear any more.
-            if (cldi(&ctl->abort.v) != 0) break;
-            const int tail0 = cldi(&ctl->node_tail.v);
-            int left = (lane < NDT_PRIM_SHARDS) ? cldi(&ctl->outstanding[lane].v) : 0;
-            const bool none_left = __ballot(left != 0) == 0ull;
-            if (none_left && cldi(&ctl->node_tail.v) == tail0) break;
-            // every fourth idle round: make work items of the partial batches at the ends of the pools
-            if ((idle_rounds & 3) == 0) stream_close_partials(ws, sa, home);
+            if (watcher) {
+                bool over = cldi(&ctl->abort.v) != 0;
+                if (!over) {
+                    const int tail0 = cldi(&ctl->node_tail.v);
+                    int left = (lane < NDT_PRIM_SHARDS) ? cldi(&ctl->outstanding[lane].v) : 0;
+                    over = __ballot(left != 0) == 0ull && cldi(&ctl->node_tail.v) == tail0;
+                }
+                if (over) {
+                    if (lane == 0) __hip_atomic_store(&wg_over, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                // every second idle round: make work items of the partial batches at the ends of the pools
+                if ((idle_rounds & 1) == 0) stream_close_partials(ws, sa, home);
+            } else if (__hip_atomic_load(&wg_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                break;
+            }
             ++idle_rounds;
             if (idle_rounds < 4) __builtin_amdgcn_s_sleep(8);
             else if (idle_rounds < 16) __builtin_amdgcn_s_sleep(32);
