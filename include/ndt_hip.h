@@ -269,6 +269,22 @@ int ndt_hip_render_multi_device(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const n
 int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_render_params *p, int32_t format,
                          void *out, ndt_render_stats *stats);
 
+/* Switches of a context.  None changes an image; they choose between equivalent ways of producing it, or turn diagnostics
+ * on.  The same names, upper-cased behind NDT_HIP_ (NDT_HIP_PIPELINE, NDT_HIP_DEBUG_LEVELS ...), are read from the
+ * environment ONCE, when the context is created; nothing on the render or upload path looks at the environment.
+ *   "pipeline"        0 auto, 1 levels (one trace launch + shade launches per bounce), 2 stream (the whole ray tree in
+ *                     one persistent launch), 3 hybrid -- DESIGN.md section 3; the environment takes the words
+ *   "hybrid_level"    hybrid: the bounce from which on the frame kernel renders (default 2)
+ *   "stream_below"    auto: passes of up to this many primaries go to the streaming frame kernel
+ *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
+ *   "shade_pair"      0: lighting of a bounce and shading of the next as two launches
+ *   "debug_levels"    profiled renders print the bounces and the duration of every trace launch
+ *   "exit_probe" / "shade_probe" / "stream_probe"   profiled renders log the life of every wavefront of the trace
+ *                     launches / of the k-th shade launch (value k + 1) / of the frame kernel
+ *   "test_small_pool" a fresh workspace starts with a node pool a reflective scene overflows (tests of the regrow path)
+ * Returns NDT_E_INVALID for a name it does not know. */
+int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t value);
+
 /* HIP devices this process sees (0 without a GPU), and the device a context lives on. */
 int ndt_hip_device_count(void);
 int ndt_hip_device(ndt_hip_ctx *ctx);

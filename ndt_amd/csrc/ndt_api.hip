@@ -2,6 +2,7 @@
 //
 // There is no CPU fallback here: without a usable HIP device every entry point fails with NDT_E_DEVICE.
 #include "ndt_ctx.hpp"
+#include <ctype.h>
 
 // ------------------------------------------------------------------ errors
 
@@ -55,11 +56,23 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ndt_hip_ctx *ctx = new ndt_hip_ctx();
     ctx->device = device;
     {
-        // which frame pipeline the context uses is fixed here, not looked up on the launch path
+        // the environment is read here, once: nothing on the render or upload path looks at it
+        static const char *const names[] = { "hybrid_level", "stream_below", "hull_box", "face_box", "shade_pair", "debug_levels",
+                                             "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
-        ctx->pipeline = !pl ? 0 : !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0;
-        if (getenv("NDT_HIP_HYBRID_LEVEL")) ctx->hybrid_level = atoi(getenv("NDT_HIP_HYBRID_LEVEL"));
-        ctx->stream_probe = getenv("NDT_HIP_STREAM_PROBE") != nullptr;
+        if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
+        for (const char *nm : names) {
+            char env[64] = "NDT_HIP_";
+            size_t k = strlen(env);
+            for (const char *q = nm; *q && k + 1 < sizeof(env); ++q) env[k++] = (char)toupper((unsigned char)*q);
+            env[k] = 0;
+            const char *v = getenv(env);
+            // (historical spellings: NDT_HIP_NO_HULL_BOX=1, NDT_HIP_NO_FACE_BOX=1, NDT_HIP_NO_SHADE_PAIR=1)
+            if (v && *v) (void)ndt_hip_set_option(ctx, nm, !strcmp(nm, "shade_probe") ? atoll(v) + 1 : atoll(v));
+        }
+        if (getenv("NDT_HIP_NO_HULL_BOX")) ctx->hull_box = false;
+        if (getenv("NDT_HIP_NO_FACE_BOX")) ctx->face_box = false;
+        if (getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR"))) ctx->shade_pair = false;
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -106,6 +119,27 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return NDT_OK;
+}
+
+extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(NDT_E_INVALID, "NULL argument");
+    const bool on = value != 0;
+    if (!strcmp(name, "pipeline")) {
+        if (value < 0 || value > 3) return fail(NDT_E_INVALID, "pipeline %lld", (long long)value);
+        ctx->pipeline = (int)value;
+    } else if (!strcmp(name, "hybrid_level")) ctx->hybrid_level = (int)value;
+    else if (!strcmp(name, "stream_below")) ctx->stream_below = value;
+    else if (!strcmp(name, "hull_box")) ctx->hull_box = on;
+    else if (!strcmp(name, "face_box")) ctx->face_box = on;
+    else if (!strcmp(name, "shade_pair")) ctx->shade_pair = on;
+    else if (!strcmp(name, "debug_levels")) ctx->debug_levels = on;
+    else if (!strcmp(name, "exit_probe")) ctx->exit_probe = on;
+    else if (!strcmp(name, "shade_probe")) ctx->shade_probe = (int)value - 1;
+    else if (!strcmp(name, "stream_probe")) ctx->stream_probe = on;
+    else if (!strcmp(name, "test_small_pool")) ctx->test_small_pool = on;
+    else return fail(NDT_E_INVALID, "unknown option '%s'", name);
     return NDT_OK;
 }
 

@@ -581,10 +581,10 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             aux1 = o.n_obj;
             std::vector<double> rows;
             HullFaces hf;
-            if (!getenv("NDT_HIP_NO_HULL_BOX") && hcube_hull_box(fs, o, n, rows, &hf)) {
+            if (ctx->hull_box && hcube_hull_box(fs, o, n, rows, &hf)) {
                 flags |= NDT_F_BOX;
                 for (double x : rows) b.push(x);
-                if (hf.n_faces > 0 && !getenv("NDT_HIP_NO_FACE_BOX")) {
+                if (hf.n_faces > 0 && ctx->face_box) {
                     // { possible-faces mask } + per face N x { centre, half extent }
                     flags |= NDT_F_FACEBOX;
                     b.push_ints((int)(hf.possible & 0xffffffffull), (int)(hf.possible >> 32));

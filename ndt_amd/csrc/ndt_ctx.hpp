@@ -78,7 +78,10 @@ struct ndt_hip_ctx {
     long long stream_below = 1100000;
     bool use_stream = false;        // the choice for the pass being rendered
     StreamArgs sa{};
-    bool stream_probe = false;      // NDT_HIP_STREAM_PROBE at context creation: profiled frames log what every wavefront did
+    // ndt_hip_set_option / NDT_HIP_* at context creation (include/ndt_hip.h)
+    bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
+    bool hull_box = true, face_box = true, shade_pair = true;
+    int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;
     int sa_nseg = 0;
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)

@@ -73,7 +73,7 @@ int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap
     if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
     if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
     if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return rc;
-    if (getenv("NDT_HIP_SHADE_PROBE") && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return rc;
+    if (ctx->shade_probe >= 0 && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return rc;
     if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
@@ -493,7 +493,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     if (cap < 2 * n_primary + 4096) cap = 2 * n_primary + 4096;
     const long long want_sh = n_primary * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1) + 4096;
     if (sh_cap < want_sh) sh_cap = want_sh;
-    if (getenv("NDT_HIP_TEST_SMALL_POOL") && ctx->ws.cap == 0) {
+    if (ctx->test_small_pool && ctx->ws.cap == 0) {
         // tests only: a fresh context starts with a node pool that a reflective scene overflows, so that the
         // overflow -> grow -> render-again path below is exercised (tests/test_gpu_parity.py)
         cap = ((n_primary + 63) & ~63LL) + 64;
@@ -598,7 +598,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             ev_end = get_event(ctx, ev_n++);
         }
         int *hc = ctx->h_counters;
-        if (prof && getenv("NDT_HIP_EXIT_PROBE"))
+        if (prof && ctx->exit_probe)
             HIP_TRY(hipMemsetAsync(ws.exit_log, 0, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS * sizeof(unsigned int), s));
         // The stream is never synchronised inside a frame: the range of every bounce is published
         // on the device (k_level_step) and read there; the host only learns, from the mailbox,
@@ -631,7 +631,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
-            static const bool exit_probe = getenv("NDT_HIP_EXIT_PROBE") != nullptr;
+            const bool exit_probe = ctx->exit_probe;
             tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
@@ -656,7 +656,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         long long upper = rg.n_primary;         // node count of the bounce
         std::vector<long long> level_nodes;
         // NDT_HIP_SHADE_PROBE=<k>: the k-th shade launch of the frame logs the life of each of its wavefronts
-        static const int shade_probe = getenv("NDT_HIP_SHADE_PROBE") ? atoi(getenv("NDT_HIP_SHADE_PROBE")) : -1;
+        const int shade_probe = ctx->shade_probe;
         int shade_launch = 0;
         long long shade_probe_finish_waves = 0;         // wavefronts of the lighting part of the probed launch
         long long shade_probe_emit_waves = 0;           // ... and of the shading part behind it (pair launches)
@@ -671,7 +671,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             }
             return w;
         };
-        static const bool fuse_shade = !(getenv("NDT_HIP_NO_SHADE_PAIR") && atoi(getenv("NDT_HIP_NO_SHADE_PAIR")));
+        const bool fuse_shade = ctx->shade_pair;
         int pending_finish = -1;                // bounce whose lighting has not been launched yet
         long long pending_upper = 0;
         // Hybrid pipeline: the first `hand` bounces -- where the rays are -- go through the per-bounce kernels (three
@@ -792,7 +792,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         else
             hipLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, ws, n_run, ctx->d_done, tag, sctl);
         HIP_TRY(hipGetLastError());
-        if (prof && getenv("NDT_HIP_DEBUG_LEVELS")) {
+        if (prof && ctx->debug_levels) {
             // the bounce table only feeds the debug output
             HIP_TRY(hipMemcpyAsync(hl, ws.levels, (size_t)(n_run + 1) * sizeof(LevelRange), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -814,7 +814,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         const unsigned long long ref_rays = ctx->h_done[5];
         const int s_overflow = (int)(long long)ctx->h_done[8], s_abort = (int)(long long)ctx->h_done[9];
         if (hc[2] != 0 || s_overflow != 0) {
-            if (getenv("NDT_HIP_DEBUG_LEVELS"))
+            if (ctx->debug_levels)
                 fprintf(stderr, "ndt_hip: overflow: per-bounce kernels %d (needs %d), frame kernel %d; pool %lld nodes, %lld shadow slots\n", hc[2],
                         hc[3], s_overflow, cap, sh_cap);
             // a pool overflowed somewhere in the frame: grow it and render again
@@ -852,7 +852,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 HIP_TRY(hipEventElapsedTime(&km, ev_k0, ev_k1));
                 print_stream_probe(sa.wave_log, km);
             }
-            if (getenv("NDT_HIP_DEBUG_LEVELS")) {
+            if (ctx->debug_levels) {
                 for (int b = 0; b < levels_used; ++b)
                     fprintf(stderr, "ndt_hip: bounce %d: %lld nodes, %lld shadow rays\n", b, hl[b].count, hl[b].n_shadow);
                 unsigned long long d[160];
@@ -896,7 +896,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                         }
                     }
                 }
-                if (getenv("NDT_HIP_EXIT_PROBE")) {
+                if (ctx->exit_probe) {
                     // the life of every wavefront of every trace launch: when the queue runs dry (first exit), how long the
                     // rest keeps going, and how much of that is the last wavefront's last batch
                     std::vector<unsigned int> log((size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS);

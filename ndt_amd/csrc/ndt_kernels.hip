@@ -487,11 +487,17 @@ __global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gbl
 #endif
 }
 
+// launch knobs of the trace kernel: environment variables in the diagnostic builds (make timing | skipknob), the defaults
+// -- compile-time constants -- in the library
+#if defined(NDT_PHASE_TIMING) || defined(NDT_TRACE_SKIP_KNOB)
 static int env_int(const char *name, int def)
 {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : def;
 }
+#else
+static constexpr int env_int(const char *, int def) { return def; }
+#endif
 
 // Workgroups of `kernel` that are resident on the device at once (occupancy x CUs).  Asked once per (device, kernel
 // variant, workgroup size, LDS bytes) and remembered: a frame has five trace launches, the query takes longer than a

@@ -888,7 +888,11 @@ static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd,
     // work items of a frame: a few per primary batch; a grid beyond that cannot help
     auto grid_for_work = [&](int res, int block) {
         long long want = (batches * 3 + (block / 64) - 1) / (block / 64) + 1;
-        return (int)(want < res ? want : res);
+        // (the kernel does not need its workgroups co-resident -- a ticket is only ever held by a running wavefront -- so a
+        // grid beyond what the occupancy query promises is safe: 256-lane workgroups are admitted two to a CU where the
+        // query says one)
+        const long long most = block <= 256 ? 2LL * res : res;
+        return (int)(want < most ? want : most);
     };
     if (tier == 0) {
         const size_t lds = (size_t)sd.trace_words * sizeof(double);

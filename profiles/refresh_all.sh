@@ -1,12 +1,27 @@
+#!/bin/bash
+# Everything the numbers in DESIGN.md / README.md come from, on one GPU box: the GPU tests, bench.py for every workload,
+# the rocprofv3 sessions (kernel stats + PMC passes -> profiles/r02_profile_*.json, which bench.py's roofline object
+# quotes when the library hash matches), the frame-time-vs-size sweep for both pipelines and the strong-scaling shard probe.
+#   gpurun --timeout 1200 -- 'bash profiles/refresh_all.sh'      then copy gpurun_out/r02_final/* of interest into profiles/
 set -u
 export TMPDIR=/tmp
 cd /root/repo 2>/dev/null || true
-mkdir -p gpurun_out/r01v8
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01v8/stats -- python3 bench.py --steps 20 --warmup 3 > gpurun_out/r01v8/bench_c3.log 2>&1 || exit 1
-bash profiles/pmc_pass.sh gpurun_out/r01v8/pmc --steps 4 --warmup 1 || exit 1
-bash profiles/pmc_pass2.sh gpurun_out/r01v8/pmc2 --steps 4 --warmup 1 || exit 1
-timeout -k 10 200 python bench.py --workload balls4d --steps 20 --warmup 3 > gpurun_out/r01v8/bench_c2.log 2>&1
-timeout -k 10 200 python bench.py --workload hypercube3d --steps 20 --warmup 3 > gpurun_out/r01v8/bench_c1.log 2>&1
-find gpurun_out/r01v8 -name "*.csv" | head -30
-bash profiles/pmc_pass3.sh gpurun_out/r01v8/pmc3 --steps 4 --warmup 1
-python3 profiles/timeline.py $(ls gpurun_out/r01v8/stats/*/*kernel_trace.csv | tail -1) > gpurun_out/r01v8/timeline.txt
+O=gpurun_out/r02_final
+mkdir -p $O
+trap "cp profiles/r02_* $O/ 2>/dev/null" EXIT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+grep "bytes differ\|noisy values" $O/tests.log > $O/test_notes.txt; tail -2 $O/tests.log
+for w in random4d balls4d hypercube3d hypercube6d hypercube7d hypercube8d; do
+  bash profiles/profile_workload.sh $w || exit 1
+done
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 > $O/bench_default.log 2>&1 || exit 1
+grep '^{' $O/bench_default.log > profiles/r02_bench_default.json.log
+for pl in levels stream; do
+  NDT_HIP_PIPELINE=$pl timeout -k 10 200 python profiles/size_probe.py > $O/size_probe_$pl.txt 2>&1
+  grep -v amdgpu $O/size_probe_$pl.txt > profiles/r02_frame_time_vs_size_$pl.txt
+done
+timeout -k 10 200 python profiles/size_probe.py 2>&1 | grep -v amdgpu > profiles/r02_frame_time_vs_size_auto.txt
+timeout -k 10 300 python profiles/shard_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > profiles/r02_shard_probe_strong.txt; cat profiles/r02_shard_probe_strong.txt
+NDT_HIP_STREAM_PROBE=1 timeout -k 10 100 python profiles/stream_probe.py random4d 64x36 960x540 2>&1 | grep -v amdgpu > profiles/r02_stream_probe_random4d.txt
+cp profiles/r02_* $O/ 2>/dev/null
+tail -1 profiles/r02_bench_default.json.log | cut -c1-400

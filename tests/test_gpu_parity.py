@@ -143,6 +143,28 @@ def test_one_frame_over_several_contexts_is_the_single_render(gpu):
             c.close()
 
 
+@pytest.mark.parametrize("name", ["c3_random4d", "zoo3d_mirror", "c1_hypercube3d", "c5_hypercube6d", "zoo4d"])
+def test_every_pipeline_renders_the_same_frame(gpu, name):
+    """The three ways a pass can be rendered -- one trace launch + shade launches per bounce (levels), the whole ray tree
+    in one persistent launch (stream), the first two bounces per bounce and the deeper ones by the frame kernel (hybrid) --
+    differ in which wavefront computes what and when, never in an operand: the images are the same to the last bit, and so
+    are the ray counts.  (zoo3d_mirror: facing mirrors, 60 bounces deep; the pools are regrown on the way.)"""
+    g = golden(name)
+    gpu.upload_scene(g.scene)
+    outs = []
+    try:
+        for pipeline in (1, 2, 3):
+            gpu.set_option("pipeline", pipeline)
+            img, st = gpu.render(g.width, g.height, g.depth)
+            outs.append((img, (st.rays_primary, st.rays_secondary, st.rays_shadow, st.rays_ref_equiv, st.levels)))
+    finally:
+        gpu.set_option("pipeline", 0)
+    for img, counts in outs[1:]:
+        assert np.array_equal(img, outs[0][0])
+        assert counts == outs[0][1]
+    assert np.abs(outs[0][0] - g.data["fb"]).max() < TOL_TIGHT
+
+
 def test_render_is_deterministic(gpu):
     g = golden("c3_random4d")
     gpu.upload_scene(g.scene)

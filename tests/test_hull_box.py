@@ -5,7 +5,7 @@ reference can return for a face lies outside the box.  Checked here
   * on the CPU: every hit the oracle reports on an hcube, for rays aimed at its faces, lies
     inside the box with the slack the derivation promises (margin 0.02 vs reach 0.01485);
   * on the GPU: the same rays give bit-identical answers with the oracle, with the boxes
-    switched off (NDT_HIP_NO_HULL_BOX=1 at upload) and with the hull box alone (NDT_HIP_NO_FACE_BOX=1).
+    switched off (ndt_hip_set_option "hull_box" 0) and with the hull box alone ("face_box" 0).
 The same holds one face at a time for the per-face boxes: only the faces whose box a ray meets are scanned.
 """
 import os
@@ -145,18 +145,14 @@ def test_cull_changes_nothing_on_the_device(oracle, name):
     try:
         gpu.upload_scene(fs)
         got = gpu.trace_rays(rays)
-        os.environ["NDT_HIP_NO_HULL_BOX"] = "1"
-        try:
-            gpu.upload_scene(fs)
-            plain = gpu.trace_rays(rays)
-        finally:
-            del os.environ["NDT_HIP_NO_HULL_BOX"]
-        os.environ["NDT_HIP_NO_FACE_BOX"] = "1"          # hull box only, every face scanned
-        try:
-            gpu.upload_scene(fs)
-            hull_only = gpu.trace_rays(rays)
-        finally:
-            del os.environ["NDT_HIP_NO_FACE_BOX"]
+        gpu.set_option("hull_box", 0)
+        gpu.upload_scene(fs)
+        plain = gpu.trace_rays(rays)
+        gpu.set_option("hull_box", 1)
+        gpu.set_option("face_box", 0)                   # hull box only, every face scanned
+        gpu.upload_scene(fs)
+        hull_only = gpu.trace_rays(rays)
+        gpu.set_option("face_box", 1)
     finally:
         gpu.close()
     for a, b, c, d in zip(got, plain, want, hull_only):
