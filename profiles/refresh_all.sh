@@ -16,12 +16,16 @@ for w in random4d balls4d hypercube3d hypercube6d hypercube7d hypercube8d; do
 done
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 > $O/bench_default.log 2>&1 || exit 1
 grep '^{' $O/bench_default.log > profiles/r02_bench_default.json.log
+for w in balls4d hypercube3d hypercube6d hypercube7d hypercube8d; do
+  NDT_HIP_PIPELINE=stream timeout -k 10 200 python bench.py --no-cpu-baseline --workload $w --steps 20 --warmup 3 2>/dev/null | grep '^{' > profiles/r02_bench_stream_$w.json.log
+done
 for pl in levels stream; do
   NDT_HIP_PIPELINE=$pl timeout -k 10 200 python profiles/size_probe.py > $O/size_probe_$pl.txt 2>&1
   grep -v amdgpu $O/size_probe_$pl.txt > profiles/r02_frame_time_vs_size_$pl.txt
 done
 timeout -k 10 200 python profiles/size_probe.py 2>&1 | grep -v amdgpu > profiles/r02_frame_time_vs_size_auto.txt
 timeout -k 10 300 python profiles/shard_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > profiles/r02_shard_probe_strong.txt; cat profiles/r02_shard_probe_strong.txt
+NDT_HIP_PIPELINE=levels timeout -k 10 200 python profiles/shard_probe.py 8 2>&1 | grep -v amdgpu > profiles/r02_shard_probe_strong_levels_n8.txt
 NDT_HIP_STREAM_PROBE=1 timeout -k 10 100 python profiles/stream_probe.py random4d 64x36 960x540 2>&1 | grep -v amdgpu > profiles/r02_stream_probe_random4d.txt
 cp profiles/r02_* $O/ 2>/dev/null
 tail -1 profiles/r02_bench_default.json.log | cut -c1-400
