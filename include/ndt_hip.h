@@ -277,6 +277,8 @@ int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_rend
  *   "hybrid_level"    hybrid: the bounce from which on the frame kernel renders (default 2)
  *   "stream_below"    auto: passes of up to this many primaries go to the streaming frame kernel
  *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
+ *   "item_sets"               0: upload a scene of up to 64 items with plain leaf lists (the kernels that read the lists,
+ *                                as for larger scenes) instead of 64-bit item sets per leaf (tests prove it neutral)
  *   "shade_pair"      0: lighting of a bounce and shading of the next as two launches
  *   "debug_levels"    profiled renders print the bounces and the duration of every trace launch
  *   "exit_probe" / "shade_probe" / "stream_probe"   profiled renders log the life of every wavefront of the trace

@@ -430,6 +430,23 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             return fail(NDT_E_UNSUPPORTED, "kd-tree depth %d exceeds the traversal stack (%d)", max_depth, NDT_KD_STACK);
     }
     sd.kd_depth = max_depth;
+    // Item sets (ndt_device.hpp:trace_kd): with at most 64 items and every list ascending in item number -- the reference's
+    // kd builder keeps the scene's object order in every leaf -- a leaf record carries its items as a 64-bit set.  Any other
+    // scene of up to 256 items takes the kernels with a four-word mask, which read the lists.
+    bool item_sets = sd.mask_words == 1 && ctx->item_sets;
+    if (item_sets) {
+        for (int i = 0; i < fs->n_kd_nodes && item_sets; ++i) {
+            const ndt_flat_kdnode &k = fs->kd_nodes[i];
+            if (k.dim >= 0) continue;
+            if (k.num < 0 || k.first < 0 || (int64_t)k.first + k.num > fs->n_leaf_refs) return fail(NDT_E_INVALID, "kd leaf %d: item range", i);
+            for (int j = 0; j < k.num; ++j) {
+                const int id = fs->leaf_refs[k.first + j];
+                if (id < 0 || id >= 64 || (j > 0 && id <= fs->leaf_refs[k.first + j - 1])) item_sets = false;
+            }
+        }
+        for (int i = 0; i < fs->n_inf; ++i)
+            if (fs->inf_refs[i] < 0 || fs->inf_refs[i] >= 64 || (i > 0 && fs->inf_refs[i] <= fs->inf_refs[i - 1])) item_sets = false;
+    }
     std::vector<int> new_index((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), -1);
     for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
     sd.n_kd_nodes = (int)order.size();
@@ -446,6 +463,17 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             b.push_ints((int)leaf_list.size(), k.num);
             for (int j = 0; j < k.num; ++j) leaf_list.push_back(fs->leaf_refs[k.first + j]);
         }
+    }
+    sd.off_nset = b.words();
+    if (item_sets) {
+        // children follow their parent in preorder: one pass from the back
+        std::vector<unsigned long long> below(order.size(), 0ull);
+        for (size_t i = order.size(); i-- > 0;) {
+            const ndt_flat_kdnode &k = fs->kd_nodes[order[i]];
+            if (k.dim >= 0) below[i] = below[i + 1] | below[(size_t)new_index[k.right]];
+            else for (int j = 0; j < k.num; ++j) below[i] |= 1ull << fs->leaf_refs[k.first + j];
+        }
+        for (unsigned long long set : below) b.push_ints((int)(set & 0xffffffffull), (int)(set >> 32));
     }
     std::vector<int> ref_patch;
     sd.off_leaf = b.push_ref_list(leaf_list, ref_patch);
@@ -729,11 +757,18 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     }
     sd.total_words = b.words();
 
-    ctx->sd = sd;
-    ctx->blob.swap(b.w);
-    ctx->n_shadow_lights = n_shadow_lights;
     // tier 0: trace sections fit the LDS budget and the visit mask fits registers
     const bool fits_lds = (size_t)sd.trace_words * sizeof(double) <= NDT_TRACE_LDS_LIMIT;
     ctx->tier = (fits_lds && sd.mask_words <= NDT_MASK_REG_WORDS) ? 0 : 1;
+    if (ctx->tier == 0 && sd.mask_words == 1) {
+        if (item_sets) {
+            for (int i = 0; i < fs->n_inf; ++i) sd.inf_bits |= 1ull << fs->inf_refs[i];
+        } else {
+            sd.mask_words = 2;          // the one-word kernels read sets: this scene takes the NDT_MASK_REG_WORDS-word ones
+        }
+    }
+    ctx->sd = sd;
+    ctx->blob.swap(b.w);
+    ctx->n_shadow_lights = n_shadow_lights;
     return NDT_OK;
 }

@@ -761,7 +761,15 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                     pr_a = wall_clock64();
                     pr_load += (unsigned int)(pr_a - pr_mark);
                 }
+#ifdef NDT_PHASE_TIMING
+                {   // (diagnostic build: the phase stamps of the per-bounce trace kernel are not collected here)
+                    unsigned long long ph[8] = {};
+                    unsigned int cnt[8] = {}, occ[8] = {};
+                    trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
+                }
+#else
                 trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+#endif
                 if (sa.wave_log) {
                     const unsigned int dt = (unsigned int)(wall_clock64() - pr_a);
                     pr_trace += dt;

@@ -30,9 +30,10 @@ if a.drop_type:
     print("dropped %d objects of type %s from the leaves" % (len(drop), a.drop_type))
 w, h = (int(x) for x in a.res.split("x"))
 g = NdtHip(0)
+g.set_option("pipeline", 1)             # the per-bounce kernels: what the phase stamps instrument
 g.upload_scene(fs)
 for i in range(3):
     g.render(w, h, a.depth)
-os.environ["NDT_HIP_DEBUG_LEVELS"] = "1"
+g.set_option("debug_levels", 1)
 out, st = g.render(w, h, a.depth, profile=1)
 print(st.as_dict())

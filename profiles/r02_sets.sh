@@ -1,0 +1,13 @@
+cd /root/repo; export TMPDIR=/tmp; O=gpurun_out/${1:-r02w}; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+for w in random4d hypercube3d balls4d; do
+  for sets in 1 0; do
+    NDT_HIP_ITEM_SETS=$sets timeout -k 10 200 python bench.py --no-cpu-baseline --workload $w --steps 30 --warmup 3 > $O/bench_${w}_$sets.log 2>&1 || { tail -3 $O/bench_${w}_$sets.log; exit 1; }
+    python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench_${w}_$sets.log") if l.startswith("{")][0])
+print("$w item_sets=$sets", "ms/step %.3f" % d["ms_per_step"], "trace %.3f ms" % d["roofline"]["avg_launch_ms"], "x%g" % d["roofline"]["launches_per_step"])
+PY
+  done
+done
+for sets in 1 0; do NDT_HIP_ITEM_SETS=$sets timeout -k 10 200 python profiles/size_probe.py 2>&1 | grep -v amdgpu > $O/size_$sets.txt; cat $O/size_$sets.txt; done

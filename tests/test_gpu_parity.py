@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import comparable, golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
+from conftest import comparable, golden, GOLDEN, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -163,6 +163,49 @@ def test_every_pipeline_renders_the_same_frame(gpu, name):
         assert np.array_equal(img, outs[0][0])
         assert counts == outs[0][1]
     assert np.abs(outs[0][0] - g.data["fb"]).max() < TOL_TIGHT
+
+
+@pytest.mark.parametrize("name", ["c3_random4d", "zoo4d", "c1_hypercube3d"])
+def test_item_sets_change_nothing(gpu, oracle, name):
+    """Scenes of up to 64 items whose leaf lists are ascending (what the reference's kd builder produces) are traced with
+    64-bit item sets per leaf instead of the lists (ndt_device.hpp:trace_kd).  Same answers and pixels as with the lists
+    ("item_sets" 0); and a scene whose leaf lists are NOT ascending must not take the set kernels: its answers are the
+    oracle's for that order."""
+    from ndt_amd import load_scene
+    g = golden(name)
+    rays = g.data["kat_in"] if "kat_in" in g.data else None
+    try:
+        gpu.upload_scene(g.scene)
+        img1, st1 = gpu.render(g.width, g.height, g.depth)
+        kat1 = gpu.trace_rays(rays) if rays is not None else None
+        gpu.set_option("item_sets", 0)
+        gpu.upload_scene(g.scene)
+        img0, st0 = gpu.render(g.width, g.height, g.depth)
+        kat0 = gpu.trace_rays(rays) if rays is not None else None
+    finally:
+        gpu.set_option("item_sets", 1)
+    assert np.array_equal(img1, img0)
+    assert (st1.rays_primary, st1.rays_secondary, st1.rays_shadow, st1.rays_ref_equiv) == (
+        st0.rays_primary, st0.rays_secondary, st0.rays_shadow, st0.rays_ref_equiv)
+    if rays is None:
+        return
+    for a, b in zip(kat1, kat0):
+        assert np.array_equal(a, b)
+    # every leaf list reversed: another scan order, other answers where it matters (ties, the dist_limit break)
+    fs = load_scene(os.path.join(GOLDEN, g.meta["scene_file"]))     # a copy of its own: the cached scene stays as it is
+    refs = list(fs.leaf_refs)
+    for k in fs.kd_nodes:
+        if k["dim"] < 0:
+            refs[k["first"]:k["first"] + k["num"]] = refs[k["first"]:k["first"] + k["num"]][::-1]
+    fs.leaf_refs = refs
+    fs._struct = None
+    fs.finalize()
+    want = oracle.trace(fs, rays)
+    gpu.upload_scene(fs)
+    got = gpu.trace_rays(rays)
+    assert np.array_equal(got[0], want[0])
+    assert np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2])
 
 
 def test_render_is_deterministic(gpu):
