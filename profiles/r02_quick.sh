@@ -1,0 +1,11 @@
+cd /root/repo; export TMPDIR=/tmp; O=gpurun_out/${1:-r02z}; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+for w in random4d hypercube3d balls4d hypercube6d; do
+    timeout -k 10 200 python bench.py --no-cpu-baseline --workload $w --steps 30 --warmup 3 > $O/bench_${w}.log 2>&1 || { tail -3 $O/bench_${w}.log; exit 1; }
+    python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench_${w}.log") if l.startswith("{")][0])
+print("$w", "ms/step %.3f" % d["ms_per_step"], "trace %.3f ms" % d["roofline"]["avg_launch_ms"], "x%g" % d["roofline"]["launches_per_step"])
+PY
+done
+timeout -k 10 200 python profiles/size_probe.py 2>&1 | grep -v amdgpu > $O/size.txt; cat $O/size.txt
