@@ -66,13 +66,13 @@ struct ndt_hip_ctx {
     // the streaming frame kernel (ndt_stream.hpp): its queues and counters live beside the workspace
     // Which pipeline renders a pass (fixed at context creation: NDT_HIP_PIPELINE=auto | levels | stream | hybrid).
     //   levels  one trace launch + shade launches per bounce: three wavefronts per SIMD in the trace kernel, shade kernels
-    //           with the whole chip's wavefront slots -- the better one where the rays are many (1080p: 1.62 ms against 1.91);
+    //           with the whole chip's wavefront slots -- the better one where the rays are many (1080p: 1.46 ms against 1.77);
     //   stream  the streaming frame kernel (ndt_stream.hpp): no per-bounce latency floor -- the better one for passes of up
-    //           to about a million primaries (64x36: 0.74 against 0.90 ms, 480x270: 0.67 against 0.83, 960x540: 0.75 against
-    //           0.98), which is also what one GPU of eight renders of a 3840x2160 frame;
+    //           to about a million primaries (64x36: 0.64 against 0.77 ms, 480x270: 0.61 against 0.72, 960x540: 0.68 against
+    //           0.85), which is also what one GPU of eight renders of a 3840x2160 frame;
     //   hybrid  the first hybrid_level bounces per bounce, the deeper ones by the frame kernel: measured, not chosen by
     //           auto (the benchmark frame has a quarter of its rays in bounces 2 and 3: 2.28 ms; hypercube 3-D 0.65 = levels);
-    //   auto    stream up to stream_below primaries, levels above.
+    //   auto    stream up to stream_below primaries (twice that for the 7-D / 8-D global-memory scenes), levels above.
     int pipeline = 0;               // 0 auto, 1 levels, 2 stream, 3 hybrid
     int hybrid_level = 2;           // hybrid: the bounce from which on the frame kernel renders (NDT_HIP_HYBRID_LEVEL)
     long long stream_below = 1100000;
