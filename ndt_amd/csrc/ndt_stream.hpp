@@ -896,16 +896,15 @@ static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd,
     // work items of a frame: a few per primary batch; a grid beyond that cannot help
     auto grid_for_work = [&](int res, int block) {
         long long want = (batches * 3 + (block / 64) - 1) / (block / 64) + 1;
-        // (the kernel does not need its workgroups co-resident -- a ticket is only ever held by a running wavefront -- so a
-        // grid beyond what the occupancy query promises is safe: 256-lane workgroups are admitted two to a CU where the
-        // query says one)
-        const long long most = block <= 256 ? 2LL * res : res;
-        return (int)(want < most ? want : most);
+        // (more workgroups than are resident would be safe -- a ticket is only ever held by a running wavefront -- but
+        // they would only start when others leave: measured with 256-lane workgroups, of which the occupancy query
+        // admits one per CU and so does the hardware, half of a 2x grid started when the frame was over)
+        return (int)(want < res ? want : res);
     };
     if (tier == 0) {
         const size_t lds = (size_t)sd.trace_words * sizeof(double);
         int lstack_block = NDT_STREAM_MAX_BLOCK;
-        if (batches < 4096) lstack_block = 256;         // a small frame is pure latency: one wavefront per SIMD
+        if (batches < 1024) lstack_block = 256;         // a small frame is pure latency: one wavefront per SIMD
 #ifdef NDT_STREAM_KNOBS
         if (getenv("NDT_STREAM_BLOCK")) lstack_block = atoi(getenv("NDT_STREAM_BLOCK"));
 #endif
