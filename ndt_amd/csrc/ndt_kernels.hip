@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 // more work instead of idling until the expensive tiles finish.  Every wavefront exits when
 // the queue head passes the ray count.
 template <int MW, bool LDS, bool LSTACK = false>
-__global__ void __launch_bounds__(NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
+__global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
     const double *blob = gblob;

@@ -204,6 +204,14 @@ extern "C" const NdtKernelTable *ndt_kernel_table_7();
 extern "C" const NdtKernelTable *ndt_kernel_table_8();
 
 #define NDT_TRACE_BLOCK 256
+// The global-memory tier (visit masks in the slab, scene in global memory: the 6-D .. 8-D hypercubes) launches
+// NDT_TRACE_BLOCK-lane workgroups; what its trace kernel is compiled for decides its registers.  For 768 lanes (168
+// registers, three wavefronts per SIMD) the 6-D / 7-D / 8-D kernels spilled 77 / 179 / 267 registers -- a vector is 2N of
+// them -- into the very memory system the tier waits for; for 512 lanes (256 registers, two per SIMD) they spill none:
+// 1080p frames 2.19 -> 2.10, 3.92 -> 3.69, 6.78 -> 6.66 ms.
+#ifndef NDT_TRACE_T1_MAX_BLOCK
+#define NDT_TRACE_T1_MAX_BLOCK 512
+#endif
 #ifndef NDT_TRACE_MAX_BLOCK
 #define NDT_TRACE_MAX_BLOCK 768
 #endif
