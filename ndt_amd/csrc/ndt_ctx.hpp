@@ -72,7 +72,7 @@ struct ndt_hip_ctx {
     //           0.85), which is also what one GPU of eight renders of a 3840x2160 frame;
     //   hybrid  the first hybrid_level bounces per bounce, the deeper ones by the frame kernel: measured, not chosen by
     //           auto (the benchmark frame has a quarter of its rays in bounces 2 and 3: 2.28 ms; hypercube 3-D 0.65 = levels);
-    //   auto    stream up to stream_below primaries (twice that for the 7-D / 8-D global-memory scenes), levels above.
+    //   auto    stream up to stream_below primaries, levels above.
     int pipeline = 0;               // 0 auto, 1 levels, 2 stream, 3 hybrid
     int hybrid_level = 2;           // hybrid: the bounce from which on the frame kernel renders (NDT_HIP_HYBRID_LEVEL)
     long long stream_below = 1100000;

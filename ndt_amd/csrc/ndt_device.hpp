@@ -837,7 +837,11 @@ struct KdStackLds {
     int stride;
 };
 
-template <int N, int MW, bool LSTACK = false>
+// UNI (the per-bounce trace kernel of the global-memory tier): where every lane of the wavefront looks at the same item --
+// coherent rays scan the same leaf in the same order: 80-90 % of the intersections of the 6-D .. 8-D scenes -- its number
+// is made a scalar, so that its records are read with scalar loads into scalar registers: no per-lane addresses, no
+// vector registers for data that is the same in all lanes (in 8-D a vector is 16 of them).  Same arithmetic.
+template <int N, int MW, bool LSTACK = false, bool UNI = false>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
@@ -1114,7 +1118,13 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         // vect_object_intersect's gate (object.c:618-624), for composites too
                         const double gate_min = in_sub ? sub_min : min_dist;
                         if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
-                        if (!(flags & NDT_F_GATE) || bsphere_gate<N>(blob, sd, id, o, v, gate_min)) {
+                        bool gate = true;
+                        if (flags & NDT_F_GATE) {
+                            const int id_u = __builtin_amdgcn_readfirstlane(id);
+                            if (UNI && __ballot(id != id_u) == 0ull) gate = bsphere_gate<N>(blob, sd, id_u, o, v, gate_min);
+                            else gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
+                        }
+                        if (gate) {
                             if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
                               // composites only occur in outer lists (validated at upload)
                               const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
@@ -1163,7 +1173,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 }
 #endif
                 double res[N], nrm[N];
-                const bool ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
+                bool ok;
+                const int prim_u = __builtin_amdgcn_readfirstlane(prim);
+                if (UNI && __ballot(prim != prim_u) == 0ull) ok = isect<N, false>(blob, sd, prim_u, o, v, res, nrm);
+                else ok = isect<N, false>(blob, sd, prim, o, v, res, nrm);
                 if (ok) {
                     NDT_COUNT(5);
                     const double dist = v_dist<N>(o, res);          // object.c:721

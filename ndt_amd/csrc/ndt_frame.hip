@@ -500,10 +500,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     }
 
     const NdtKernelTable *kt = ctx->kt;
-    // auto: the frame kernel up to stream_below primaries; twice that for the big global-memory scenes (7-D / 8-D hypercubes:
-    // batches of 150-300 us, so the queues cost nothing and the per-bounce launches' tails are long: 1080p 3.58 against
-    // 3.85 ms and 6.53 against 6.69; profiles/r02_frame_time_vs_size_hypercube*.txt)
-    const long long stream_upto = ctx->stream_below * ((ctx->tier == 1 && ctx->sd.mask_words >= 16) ? 2 : 1);
+    const long long stream_upto = ctx->stream_below;
     ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= stream_upto);
     const bool hybrid = !ctx->use_stream && ctx->pipeline == 3 && ctx->hybrid_level >= 1 && rg.max_depth > ctx->hybrid_level;
     if (ctx->use_stream) {

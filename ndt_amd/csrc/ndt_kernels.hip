@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 // more work instead of idling until the expensive tiles finish.  Every wavefront exits when
 // the queue head passes the ray count.
 template <int MW, bool LDS, bool LSTACK = false>
-__global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_MAX_BLOCK) k_trace(const double *gblob, SceneDesc sd, Workspace ws, TraceJob job)
+__global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_MAX_BLOCK) k_trace(const double *__restrict__ gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
     const double *blob = gblob;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;     // keeps the loads alive
             prim = -1;
         } else
-        trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
+        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
         out_last = __builtin_readcyclecounter();
         if (ws.dbg && lane == __ffsll((long long)__ballot(1)) - 1) {
             // duration of this batch inside trace_kd: slowest batch of the launch (dbg[40 + is_shadow])
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             prim = -1;
         } else
 #endif
-        trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, kstack);
 #endif
 #ifdef NDT_TRACE_SKIP_KNOB
         if (job.skip_trace == 2 && obj == -1) continue;
