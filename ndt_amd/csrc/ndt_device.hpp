@@ -1089,66 +1089,83 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 } else if (!in_sub && (BITS ? cand == 0ull : pos == end)) {
                     scanning = false;       // list exhausted
                 } else {
-                    int id, flags;
-                    bool fresh = true;
-                    if (BITS && !in_sub) {
-                        const unsigned long long bit = cand & (0ull - cand);        // the lowest item of the set
-                        id = __ffsll((long long)cand) - 1;
-                        cand ^= bit;
-                        if (!list_is_inf) mask.w[0] |= bit;                         // object.c:713
-                        flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
-                    } else {
-                        blob_ref(blob, in_sub ? sd.off_child + sub_i : sec + pos, id, flags);
-                    }
-                    if (in_sub) {
-                        // on to the next face whose box the ray meets (arithmetic shifts: all ones stays all ones)
-                        const long long rest = sub_live >> 1;
-                        if (rest == 0) {
-                            sub_i = sub_end;
-                        } else {
-                            const int skip = __ffsll(rest) - 1;
-                            sub_i += 1 + skip;
-                            sub_live = rest >> skip;
-                        }
-                    } else if (!BITS) {
-                        pos += 1;
-                    }
-                    if (!BITS && !in_sub && !list_is_inf) fresh = !mask.test_and_set(id);    // object.c:707-713
-                    if (fresh) {
-                        // vect_object_intersect's gate (object.c:618-624), for composites too
-                        const double gate_min = in_sub ? sub_min : min_dist;
-                        if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
-                        bool gate = true;
-                        if (flags & NDT_F_GATE) {
-                            const int id_u = __builtin_amdgcn_readfirstlane(id);
-                            if (UNI && __ballot(id != id_u) == 0ull) gate = bsphere_gate<N>(blob, sd, id_u, o, v, gate_min);
-                            else gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
-                        }
-                        if (gate) {
-                            if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
-                              // composites only occur in outer lists (validated at upload)
-                              const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
-                              const int nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
-                              long long live = -1;
-                              if (flags & NDT_F_BOX)
-                                  live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1),
-                                                       (flags & NDT_F_FACEBOX) != 0, nf, o, v);
-                              if (live != 0) {
-                                const int skip = __ffsll(live) - 1;
-                                in_sub = true;
-                                sub_owner = id;
-                                sub_i = first + skip;
-                                sub_end = first + nf;
-                                sub_live = live >> skip;
-                                sub_min = -1;
-                                sub_prim = -1;
-                              }
-                            } else {
-                                prim = id;
-                                scanning = false;
-                                if (in_sub) NDT_COUNT(2); else NDT_COUNT(4);
+                    // one item of the list: visit mark, gate, and what passing the gate leads to
+                    auto scan_item = [&](const int id, const int flags, const bool masked) {
+                        bool fresh = true;
+                        if (masked) fresh = !mask.test_and_set(id);                             // object.c:707-713
+                        if (fresh) {
+                            // vect_object_intersect's gate (object.c:618-624), for composites too
+                            const double gate_min = in_sub ? sub_min : min_dist;
+                            if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
+                            bool gate = true;
+                            if (flags & NDT_F_GATE) gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
+                            if (gate) {
+                                if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
+                                    // composites only occur in outer lists (validated at upload)
+                                    const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
+                                    const int nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+                                    long long live = -1;
+                                    if (flags & NDT_F_BOX)
+                                        live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1),
+                                                             (flags & NDT_F_FACEBOX) != 0, nf, o, v);
+                                    if (live != 0) {
+                                        const int skip = __ffsll(live) - 1;
+                                        in_sub = true;
+                                        sub_owner = id;
+                                        sub_i = first + skip;
+                                        sub_end = first + nf;
+                                        sub_live = live >> skip;
+                                        sub_min = -1;
+                                        sub_prim = -1;
+                                    }
+                                } else {
+                                    prim = id;
+                                    scanning = false;
+                                    if (in_sub) NDT_COUNT(2); else NDT_COUNT(4);
+                                }
                             }
                         }
+                    };
+                    // UNI: every active lane stands on the same entry of the same outer list (coherent rays): the entry, the
+                    // item's header flags and its bounding sphere are then scalars, read with scalar loads; the branches on
+                    // them are scalar branches.  Same steps, same order.
+                    bool together = false;
+                    int w_u = 0;
+                    if (UNI && !BITS) {
+                        const int w = sec + pos;
+                        w_u = __builtin_amdgcn_readfirstlane(w);
+                        together = __ballot(in_sub || w != w_u) == 0ull;
+                    }
+                    if (together) {
+                        int id, flags;
+                        blob_ref(blob, w_u, id, flags);
+                        pos += 1;
+                        scan_item(id, flags, !list_is_inf);
+                    } else {
+                        int id, flags;
+                        if (BITS && !in_sub) {
+                            const unsigned long long bit = cand & (0ull - cand);        // the lowest item of the set
+                            id = __ffsll((long long)cand) - 1;
+                            cand ^= bit;
+                            if (!list_is_inf) mask.w[0] |= bit;                         // object.c:713
+                            flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
+                        } else {
+                            blob_ref(blob, in_sub ? sd.off_child + sub_i : sec + pos, id, flags);
+                        }
+                        if (in_sub) {
+                            // on to the next face whose box the ray meets (arithmetic shifts: all ones stays all ones)
+                            const long long rest = sub_live >> 1;
+                            if (rest == 0) {
+                                sub_i = sub_end;
+                            } else {
+                                const int skip = __ffsll(rest) - 1;
+                                sub_i += 1 + skip;
+                                sub_live = rest >> skip;
+                            }
+                        } else if (!BITS) {
+                            pos += 1;
+                        }
+                        scan_item(id, flags, !BITS && !in_sub && !list_is_inf);
                     }
                 }
             }
