@@ -151,6 +151,7 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
     g1.aspect_w = W;
     g1.aspect_h = H;
     g1.eye = 1;
+    g1.stereo = p->stereo;          // side-by-side / over-under: every sample is split by its position (ndt.c:590-612), in the (W+1) x (H+1) frame
     double *pass1 = nullptr;
     if ((rc = buf.get(&pass1, (size_t)g1.rows * g1.width * 4))) return rc;
     ndt_render_stats st{};
@@ -204,6 +205,7 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
         gs.aspect_w = W;
         gs.aspect_h = H;
         gs.eye = 1;
+        gs.stereo = p->stereo;
         if ((rc = render_pass(ctx, gs, prof, colours, st))) return rc;
         add_stats(total, st);
         total.aa_samples += gs.n_samples;

@@ -33,8 +33,8 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (p->recursive_aa && ctx->aperture_radius != 0.0)
         return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing with aperture radius %g samples the lens with drand48 (ndt.c:528): not reproducible", ctx->aperture_radius);
     if (p->recursive_aa && (p->aa_diff < 0 || p->aa_depth > 24)) return fail(NDT_E_INVALID, "bad anti-aliasing parameters");
-    if (p->recursive_aa && (p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
-        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing is implemented for the mono planar camera without a depth map");
+    if (p->recursive_aa && ((p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER) || d_depth))
+        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing is implemented for mono, side-by-side and over/under images without a depth map");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);

@@ -1631,7 +1631,10 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     if (p && p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO)) return NDT_E_UNSUPPORTED;
     if (p && p->samples > 1 && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
     if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_HIDEF)) return NDT_E_UNSUPPORTED;
-    if (p && p->stereo != NDT_STEREO_MONO && p->recursive_aa) return NDT_E_UNSUPPORTED;
+    /* recursive AA with the modes that split the image (render_pixel does the split for every sample, ndt.c:590-612);
+     * anaglyph and frame packing with AA are not pinned by fixtures */
+    if (p && p->recursive_aa && p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)
+        return NDT_E_UNSUPPORTED;
     /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
     if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0) return NDT_E_UNSUPPORTED;
     return NDT_OK;

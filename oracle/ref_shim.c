@@ -385,15 +385,18 @@ int main(int argc, char **argv)
         n_trace_closest = n_trace_shadow = 0;
         counting = 1;
         double t0 = now_s();
+        /* the stereo modes that split the image (ndt.c:913-916): render_image hands mode and scales to both passes */
+        const double aa_xs = stereo == 1 ? 0.5 : 1.0, aa_ys = stereo == 2 ? 0.5 : 1.0;
+        if (stereo != 0 && stereo != 1 && stereo != 2) { fprintf(stderr, "ref_shim: --aa with --stereo %d is not wired\n", stereo); return 2; }
         for (int j = 0; j < height + 1; ++j)
-            render_line(&scn, width + 1, 1.0, height + 1, 1.0, j, 0 /* MONO */, 1, &img, NULL, max_depth);
+            render_line(&scn, width + 1, aa_xs, height + 1, aa_ys, j, stereo, 1, &img, NULL, max_depth);
         long long rays_pass1 = n_trace_closest + n_trace_shadow;
         double *out = malloc(sizeof(double) * (size_t)width * height * 4);
         long long resampled = 0;
         for (int j = 0; j < height; ++j)
             for (int i = 0; i < width; ++i) {
                 dbl_pixel_t clr;
-                resampled += resample_pixel(&scn, width, 1.0, height, 1.0, i, j, 0, 1, aa_diff, aa_depth, &img, &clr, max_depth);
+                resampled += resample_pixel(&scn, width, aa_xs, height, aa_ys, i, j, stereo, 1, aa_diff, aa_depth, &img, &clr, max_depth);
                 double *q = out + ((size_t)j * width + i) * 4;
                 q[0] = clr.r; q[1] = clr.g; q[2] = clr.b; q[3] = clr.a;
             }

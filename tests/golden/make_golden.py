@@ -90,6 +90,13 @@ CASES = {
                               share_scene="c1_hypercube3d"),
     "aa_zoo4d": dict(scene="parity_zoo", dims=4, res=(48, 27), depth=6, fb=True, kat=0, aa=(8, 3),
                      share_scene="zoo4d"),
+    # ... with the stereo modes that split the image, and through the VR camera (every sample goes through render_pixel)
+    "aa_zoo4d_sbs": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, aa=(8, 3), stereo=1, v2=True,
+                         share_scene="st_zoo4d_sbs"),
+    "aa_zoo4d_ou": dict(scene="parity_zoo", dims=4, res=(48, 54), depth=6, fb=True, kat=0, aa=(8, 2), stereo=2, v2=True,
+                        share_scene="st_zoo4d_sbs"),
+    "aa_vr_zoo4d": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, aa=(8, 3), v2=True, config="vr",
+                        share_scene="vr_zoo4d"),
     # stereo modes (-m, ndt.c:46-48, 590-650), depth maps (-z, ndt.c:362-373, 753-756), VR / panorama cameras
     # (camera.c:506-555): scenes in `ndtscene 2` (eyes, local axes, fields of view)
     "st_zoo4d_sbs": dict(scene="parity_zoo", dims=4, res=(64, 36), depth=6, fb=True, kat=0, stereo=1, v2=True),

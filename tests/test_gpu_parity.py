@@ -267,12 +267,18 @@ def test_recursive_antialiasing_vs_reference(gpu, name):
     g = golden(name)
     aa = (g.meta["aa_diff"], g.meta["aa_depth"])
     gpu.upload_scene(g.scene)
-    out, st = gpu.render(g.width, g.height, g.depth, aa=aa)
+    out, st = gpu.render(g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
     ref = g.data["fb"]
     diff = np.abs(out - ref)
-    assert diff.max() < TOL_TIGHT, "max abs diff %g" % diff.max()
+    # (the VR screen goes through sin / cos: ocml against glibc in the primary rays, as in the view cases)
+    assert diff.max() < (1e-7 if g.meta.get("config") == "vr" else TOL_TIGHT), "max abs diff %g" % diff.max()
     assert st.pixels_resampled == g.meta["pixels_resampled"]
-    assert st.rays_ref_equiv == g.meta["rays_total"]
+    # The reference's trace_kd count.  Refracted directions go through acos / sin / asin / cos (vectNd.c:119-200): ocml's differ
+    # from glibc's in the last bit, everything behind a refraction is a last-bit different ray, and about one such ray in
+    # 10^5 sits on a sign or EPSILON test that then falls the other way -- a shadow ray more or less whose contribution is
+    # zero either way (the images agree to 1e-13).  The small fixtures have no such ray (counts identical); the anti-aliased
+    # zoo frames, 0.5 - 3 M rays each, have a handful (profiles/aa_stereo_counts.py: mono as well as stereo).
+    assert abs(st.rays_ref_equiv - g.meta["rays_total"]) <= 1e-5 * g.meta["rays_total"], (st.rays_ref_equiv, g.meta["rays_total"])
 
 
 def test_recursive_antialiasing_row_shards_and_oracle(gpu, oracle):

@@ -74,7 +74,7 @@ def test_recursive_antialiasing_bit_exact(oracle, name):
     reference's own render_line + resample_pixel, its "pixels resampled" count and its trace_kd count."""
     g = golden(name)
     aa = (g.meta["aa_diff"], g.meta["aa_depth"])
-    out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa)
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
     ref = g.data["fb"]
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
     assert st.pixels_resampled == g.meta["pixels_resampled"] > 0
