@@ -176,7 +176,7 @@ typedef struct ndt_render_params {
     int32_t recursive_aa;       /* 0 = off */
     int32_t aa_diff;            /* reference default 20 (ndt.c:1412) */
     int32_t aa_depth;           /* reference default 4 (ndt.c:1411) */
-    int32_t stereo;             /* ndt_stereo_mode (needs the eyes in the flat scene); not with recursive_aa */
+    int32_t stereo;             /* ndt_stereo_mode (needs the eyes in the flat scene); with recursive_aa: mono, side-by-side, over/under */
     int32_t reserved[4];        /* must be 0 */
 } ndt_render_params;
 
