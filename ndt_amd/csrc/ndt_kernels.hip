@@ -111,11 +111,13 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
         ws.hit_obj[g] = -1;
         return;
     }
+    // (jittered samples: the PIXEL decides the half, the jitter comes after -- i + dx/2 and j - dy/2 lie in [i, i+1) and (j-1, j])
+    const double half_i = rg.raw_samples ? floor(ip) : ip, half_j = rg.raw_samples ? ceil(jp) : jp;
     if (rg.stereo == 1) {           // SIDE_SIDE_3D, x_scale = 0.5 (ndt.c:591-601)
-        if (ip < rg.img_w / 2) { ip = ip / 0.5; eye = 0; }
+        if (half_i < rg.img_w / 2) { ip = ip / 0.5; eye = 0; }
         else { ip = (ip - rg.img_w / 2) / 0.5; eye = 2; }
     } else if (rg.stereo == 2) {    // OVER_UNDER_3D, y_scale = 0.5 (ndt.c:602-612)
-        if (jp < rg.img_h / 2) { jp = jp / 0.5; eye = 0; }
+        if (half_j < rg.img_h / 2) { jp = jp / 0.5; eye = 0; }
         else { jp = (jp - rg.img_h / 2) / 0.5; eye = 2; }
     }
     double y_div = (double)rg.img_h;

@@ -21,8 +21,8 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
     if (p->samples < 1) return fail(NDT_E_INVALID, "samples=%d", p->samples);
     const bool stochastic = p->samples > 1 || ctx->has_area_lights;
-    if (stochastic && (p->recursive_aa || p->stereo != NDT_STEREO_MONO || d_depth || ctx->cam_type != 0))
-        return fail(NDT_E_UNSUPPORTED, "samples > 1 and area lights are implemented for the mono planar camera without recursive anti-aliasing or a depth map");
+    if (stochastic && (p->recursive_aa || d_depth || (p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)))
+        return fail(NDT_E_UNSUPPORTED, "samples > 1 and area lights are implemented for mono, side-by-side and over/under images without recursive anti-aliasing or a depth map");
     if (p->samples > 1 && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
         return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");

@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned long long ns_sample_key(unsigned long long p
 // sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
 // (`per` consecutive samples per pixel in one pass: sample a*per + r is the pixel's sample number round + r)
 __global__ void k_ns_samples(const int *active, int n_active, int per, int width, int row_begin, int row_step, unsigned int round0,
-                             double aperture, int jitter, double *samples, unsigned long long *keys)
+                             double aperture, int jitter, double xs, double ys, double *samples, unsigned long long *keys)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= (long long)n_active * per) return;
@@ -43,8 +43,11 @@ __global__ void k_ns_samples(const int *active, int n_active, int per, int width
         } while (ax * ax + ay * ay > 1.0 && k < 1064);
     }
     double *q = samples + 4ll * a;
-    q[0] = i + dx;          // x = orig_x + dx/width
-    q[1] = j - dy;          // y = orig_y + dy/height, and y grows upwards
+    // x = orig_x + dx/width, y = orig_y + dy/height (y grows upwards).  The jitter is added AFTER render_pixel has split a
+    // side-by-side / over-under image (ndt.c:590-612 before :505-514): in the squeezed direction it spans 1/width of the
+    // eye's image, half a pixel of the packed one -- xs / ys = 0.5 there, so that k_primary's "/ 0.5" gives it back whole
+    q[0] = i + dx * xs;
+    q[1] = j - dy * ys;
     q[2] = ax * aperture;
     q[3] = ay * aperture;
 }
@@ -151,7 +154,8 @@ int ndt_impl::render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void 
         }
         const unsigned g_act = (unsigned)((n_active + 255) / 256);
         hipLaunchKernelGGL(k_ns_samples, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, list[flip], n_active, (int)per, W,
-                           p->row_begin, p->row_step, round, ctx->aperture_radius, p->samples > 1 ? 1 : 0, samples, keys);
+                           p->row_begin, p->row_step, round, ctx->aperture_radius, p->samples > 1 ? 1 : 0,
+                           p->stereo == NDT_STEREO_SIDE_SIDE ? 0.5 : 1.0, p->stereo == NDT_STEREO_OVER_UNDER ? 0.5 : 1.0, samples, keys);
         RenderGeom gs{};
         gs.samples = samples;
         gs.n_samples = (int)n_s;
@@ -165,6 +169,7 @@ int ndt_impl::render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void 
         gs.aspect_w = W;
         gs.aspect_h = H;
         gs.eye = 1;
+        gs.stereo = p->stereo;
         gs.lens = 1;
         gs.raw_samples = 1;
         gs.sample_keys = keys;

@@ -1628,7 +1628,8 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     if (p && (p->samples < 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
         return NDT_E_INVALID;
     /* samples > 1: jitter + lens sampling from drand48 (ndt.c:505-542); not combined with the other modes here */
-    if (p && p->samples > 1 && (p->recursive_aa || p->stereo != NDT_STEREO_MONO)) return NDT_E_UNSUPPORTED;
+    if (p && p->samples > 1 && (p->recursive_aa || (p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)))
+        return NDT_E_UNSUPPORTED;
     if (p && p->samples > 1 && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
     if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_HIDEF)) return NDT_E_UNSUPPORTED;
     /* recursive AA with the modes that split the image (render_pixel does the split for every sample, ndt.c:590-612);

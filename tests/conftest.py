@@ -125,5 +125,5 @@ FULL_CASES = ["c1_hypercube3d_256", "c2_balls4d_1080p", "c3_random4d_1080p", "c4
               "c5_hypercube7d_1080p", "c5_hypercube8d_1080p"]
 AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d", "aa_zoo4d_sbs", "aa_zoo4d_ou", "aa_vr_zoo4d"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
-SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3"]   # -n samples > 1 and / or area lights
+SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3", "ns_zoo4d_sbs", "ns_vr_zoo4d"]   # -n samples > 1 and / or area lights
 VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "st_zoo3d_hidef", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

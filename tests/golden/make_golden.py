@@ -116,6 +116,11 @@ CASES = {
     # fresh process (default seed): reproducible, and the oracle walks the same stream
     "ns_c3_random4d": dict(scene="random", dims=4, res=(32, 18), depth=4, fb=True, kat=0, samples=4, share_scene="c3_random4d"),
     "ns_zoo4d_dof": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, samples=6, v2=True, config="dof"),
+    # ... in a side-by-side image (the jitter is added after render_pixel's split) and through the VR camera
+    "ns_zoo4d_sbs": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, samples=4, stereo=1, v2=True,
+                         share_scene="st_zoo4d_sbs"),
+    "ns_vr_zoo4d": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, samples=4, v2=True, config="vr",
+                        share_scene="vr_zoo4d"),
     # area lights (LIGHT_DISK / LIGHT_RECT, ndt.c:116-147): a random point of the light per shading evaluation, so even
     # -n 1 is stochastic (the adaptive loop's repeats differ); the second case adds jitter and a lens
     "al_zoo4d": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=5, fb=True, kat=0, samples=1, v2=True, config="area"),

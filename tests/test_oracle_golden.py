@@ -117,6 +117,7 @@ def test_jittered_samples_and_lens_bit_exact(oracle, name):
     there and walks the pixels in the same order, so it draws the same numbers: same image, same
     trace_kd count."""
     g = golden(name)
-    out, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"])
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"],
+                            stereo=g.meta.get("stereo", 0))
     assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
     assert st.rays_ref_equiv == g.meta["rays_total"]
