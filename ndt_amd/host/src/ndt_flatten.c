@@ -36,7 +36,11 @@ static int add_object(ndt_flat_builder *fb, object *o, int parent, int dims, cha
     if (type >= NDT_OBJ_TYPE_COUNT) {
         char tn[OBJ_TYPE_MAX_LEN] = "";
         o->type_name(tn, sizeof(tn));
-        snprintf(err, (size_t)err_len, "object '%s' has type '%s', which has no device implementation", o->name, tn);
+        const char *file = ndt_object_plugin_file(tn);
+        if (file)
+            snprintf(err, (size_t)err_len, "object '%s' has type '%s' from the plugin '%s': its intersect() is host code and cannot run on the device", o->name, tn, file);
+        else
+            snprintf(err, (size_t)err_len, "object '%s' has type '%s', which has no device implementation", o->name, tn);
         return -1;
     }
     if (!ndt_object_has_default_material(o)) {

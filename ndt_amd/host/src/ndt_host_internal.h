@@ -7,6 +7,7 @@
 #define NDT_TYPE_CLUSTER 100
 #define NDT_TYPE_OTHER 101
 
+const char *ndt_object_plugin_file(const char *type);    /* file of a host-side-only plugin type, or NULL */
 int ndt_object_type_id(object *o);                  /* NDT_OBJ_* for device types, else NDT_TYPE_* */
 int ndt_object_has_default_material(object *o);
 void ndt_hcube_prepare(object *cube);

@@ -298,6 +298,7 @@ int main(int argc, char **argv)
     int samples = 1;        /* -n (ndt.c:1574-1577) */
     int stereo = 0, specular = 1, want_depth = 0;      /* -m, -p, -z (ndt.c:1533-1573, 1581-1589, 1726-1729) */
     char *scene_path = NULL, *config = NULL, *dump_path = NULL, *raw_path = NULL;
+    char *objects_dir = "objects";      /* -o: where object plugins are looked for (object.c:119; ndt.c passes "objects") */
     static struct option longopts[] = { { "dump-scene", required_argument, NULL, 1000 },
                                         { "raw", required_argument, NULL, 1001 }, { "png", no_argument, NULL, 1002 },
                                         { NULL, 0, NULL, 0 } };
@@ -345,7 +346,7 @@ int main(int argc, char **argv)
         case 's': scene_path = optarg; break;
         case 't': threads = atoi(optarg); break;
         case 'u': config = optarg; break;
-        case 'o': break;    /* object plugins are built in */
+        case 'o': objects_dir = optarg; break;    /* object.c:119: a directory of object plugins (the built-in types need none) */
         case 1000: dump_path = optarg; break;
         case 1001: raw_path = optarg; break;
         case 1002: png = 1; break;
@@ -376,7 +377,7 @@ int main(int argc, char **argv)
     if (!setup) { fprintf(stderr, "%s has no scene_setup\n", scene_path); return 1; }
     if (frame_count && !frames_given) frames = frame_count(dims, config);
     if (last < 0) last = frames - 1;
-    register_objects("objects");
+    register_objects(objects_dir);
 
     job_opts.dims = dims; job_opts.width = width; job_opts.height = height; job_opts.depth = depth; job_opts.threads = threads;
     job_opts.aa_diff = aa_diff; job_opts.aa_depth = aa_depth; job_opts.stereo = stereo; job_opts.specular = specular;

@@ -6,6 +6,9 @@
  * host has to reproduce exactly is everything that decides *which* tests the device makes:
  * bounding points -> bounding spheres and kd item boxes -> tree shape and leaf order. */
 #include <strings.h>
+#include <dirent.h>
+#include <dlfcn.h>
+#include <limits.h>
 
 #include "ndt_host_api.h"
 #include "ndt_host_internal.h"
@@ -300,15 +303,121 @@ static const type_entry type_table[] = {
 };
 static const int n_types = (int)(sizeof(type_table) / sizeof(type_table[0]));
 
-int register_objects(char *dirname) { (void)dirname; return 0; }
-int unregister_objects(void) { return 0; }
+/* Object plugins (object.c:51-153).  The nine types the device intersects, `cluster` and `stubs` are built in, in the
+ * table above.  register_objects(dir) additionally dlopens every .so of a directory the way the reference does and asks it
+ * for its type_name (object.c:60-111 names the same five entry points):
+ *   - a plugin whose type is built in (the reference's own objects/sphere.so ...) is acknowledged and closed again: the
+ *     built-in host functions and the device intersector stand for it;
+ *   - a plugin with a type of its own is kept: object_alloc() of that type works, with the plugin's params and
+ *     bounding_points, so a scene program that uses it builds its scene; rendering refuses it by name (ndt_flatten.c:
+ *     a foreign intersect() cannot run on the device -- DESIGN.md, section 7). */
+typedef struct plugin_type {
+    struct plugin_type *next;
+    char name[OBJ_TYPE_MAX_LEN];
+    char file[256];
+    void *dl;
+    int (*type_name)(char *, int);
+    int (*params)(PARAMS_ARGS);
+    int (*bounding_points)(object *, bounds_list *);
+    int (*cleanup)(object *);
+} plugin_type;
+static plugin_type *plugins = NULL;
+static int n_plugins = 0;
+
+int register_object(char *filename)
+{
+    void *dl = dlopen(filename, RTLD_NOW);
+    if (!dl) {
+        fprintf(stderr, "%s\n", dlerror());
+        return -1;
+    }
+    plugin_type *e = (plugin_type *)calloc(1, sizeof(*e));
+    *(void **)(&e->type_name) = dlsym(dl, "type_name");
+    *(void **)(&e->params) = dlsym(dl, "params");
+    *(void **)(&e->bounding_points) = dlsym(dl, "bounding_points");
+    *(void **)(&e->cleanup) = dlsym(dl, "cleanup");
+    void *isect = dlsym(dl, "intersect");
+    const char *missing = !e->type_name ? "type_name" : !e->params ? "params" : !e->bounding_points ? "bounding_points" : !isect ? "intersect" : NULL;
+    if (missing) {                          /* object.c:86-101 */
+        fprintf(stderr, "%s missing %s function.\n", filename, missing);
+        dlclose(dl);
+        free(e);
+        return -1;
+    }
+    e->type_name(e->name, sizeof(e->name));
+    const char *base = strrchr(filename, '/');
+    base = base ? base + 1 : filename;
+    for (int i = 0; i < n_types; ++i)
+        if (!strcasecmp(type_table[i].name, e->name)) {
+            printf("\tobject type '%s' from '%s': built in (device intersector).\n", e->name, base);
+            dlclose(dl);
+            free(e);
+            return 0;
+        }
+    for (plugin_type *q = plugins; q; q = q->next)
+        if (!strcasecmp(q->name, e->name)) {        /* loaded before */
+            dlclose(dl);
+            free(e);
+            return 0;
+        }
+    snprintf(e->file, sizeof(e->file), "%s", base);
+    e->dl = dl;
+    e->next = plugins;
+    plugins = e;
+    ++n_plugins;
+    printf("\tloaded object type '%s' from '%s': host side only (no device intersector: scenes that use it cannot be rendered).\n", e->name, base);
+    return 0;
+}
+
+int register_objects(char *dirname)
+{
+    if (!dirname) {
+        fprintf(stderr, "%s: dirname is NULL\n", __func__);
+        return -1;
+    }
+    DIR *d = opendir(dirname);
+    if (!d) return 0;           /* no plugin directory: the built-in types are all there is (the reference would stop here) */
+    struct dirent *dp;
+    while ((dp = readdir(d)) != NULL) {
+        const size_t len = strlen(dp->d_name);
+        if (len > 3 && !strncasecmp(dp->d_name + len - 3, ".so", 3)) {
+            char path[PATH_MAX];
+            snprintf(path, sizeof(path), "%s/%s", dirname, dp->d_name);     /* avoid the library search path (object.c:146) */
+            register_object(path);
+        }
+    }
+    closedir(d);
+    return 0;
+}
+
+int unregister_objects(void)
+{
+    while (plugins) {
+        plugin_type *e = plugins;
+        plugins = e->next;
+        dlclose(e->dl);
+        free(e);
+    }
+    n_plugins = 0;
+    return 0;
+}
+
+/* the file a host-side-only type came from (for messages), or NULL for a built-in type */
+const char *ndt_object_plugin_file(const char *type)
+{
+    for (plugin_type *q = plugins; q; q = q->next)
+        if (!strcasecmp(q->name, type)) return q->file;
+    return NULL;
+}
 
 int registered_types(char ***list, int *num)
 {
-    *num = n_types;
-    *list = (char **)calloc((size_t)n_types + 1, sizeof(char *));
+    *num = n_types + n_plugins;
+    *list = (char **)calloc((size_t)*num + 1, sizeof(char *));
     if (!*list) { *num = -1; return -1; }
     for (int i = 0; i < n_types; ++i) (*list)[i] = strdup(type_table[i].name);
+    int k = n_types;            /* the built-in order first (scenes/random.c indexes the list), plugins behind it */
+    for (plugin_type *q = plugins; q; q = q->next) (*list)[k++] = strdup(q->name);
     return *num;
 }
 
@@ -337,8 +446,18 @@ int ndt_object_type_id(object *o)
 object *object_alloc(int dimensions, char *type, char *name)
 {
     const type_entry *t = NULL;
+    type_entry from_plugin;
     for (int i = 0; i < n_types && !t; ++i)
         if (!strcasecmp(type_table[i].name, type)) t = &type_table[i];
+    for (plugin_type *q = plugins; q && !t; q = q->next)
+        if (!strcasecmp(q->name, type)) {
+            from_plugin.name = q->name;
+            from_plugin.type_name = q->type_name;
+            from_plugin.params = q->params;
+            from_plugin.bounding_points = q->bounding_points;
+            from_plugin.cleanup = q->cleanup;
+            t = &from_plugin;
+        }
     if (!t) {
         fprintf(stderr, "Unknown object type '%s'.\n", type);
         exit(1);                                /* the reference's behaviour (object.c:233-236); scenes rely on it */

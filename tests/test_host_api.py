@@ -233,3 +233,62 @@ def test_one_frame_over_several_gpu_contexts_from_the_c_driver(driver, tmp_path)
         assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
         outs.append((np.fromfile(str(d / "fb.f64")), [q.read_bytes() for q in sorted((d / "images").rglob("*.ppm"))]))
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and len(outs[0][1]) == 1
+
+
+def _compile_against_host_api(tmp_path, src, out, extra=()):
+    """scene programs and object plugins say #include "../scene.h" / "../object.h": lay the tree out so that resolves to
+    this repository's host headers"""
+    sub = tmp_path / "src"
+    sub.mkdir(exist_ok=True)
+    for h in os.listdir(os.path.join(HOST, "include")):
+        if not os.path.exists(tmp_path / h):
+            os.symlink(os.path.join(HOST, "include", h), tmp_path / h)
+    dst = sub / os.path.basename(src)
+    if not os.path.exists(dst):
+        os.symlink(src, dst)
+    r = subprocess.run(["gcc", "-O2", "-std=c99", "-D_GNU_SOURCE", "-fPIC", "-shared", "-Wall", *extra, "-o", out, str(dst)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_object_plugins_are_loaded_and_foreign_types_are_refused_by_name(driver, tmp_path):
+    """register_objects (object.c:119-153): `-o dir` dlopens every .so of the directory.  A plugin whose type is one of the
+    built-in ones stands for the built-in implementation (its scene flattens like any other); a plugin with a type of its
+    own loads host-side -- a scene program can allocate it, it gets its bounding sphere and its place in the kd-tree --
+    and rendering refuses it by type and file: its intersect() is host code."""
+    plug = os.path.join(ROOT, "tests", "plugins")
+    objs = tmp_path / "objects"
+    objs.mkdir()
+    _compile_against_host_api(tmp_path, os.path.join(plug, "blob.c"), str(objs / "blob.so"), ['-DNDT_TEST_PLUGIN_TYPE="blob"'])
+    _compile_against_host_api(tmp_path, os.path.join(plug, "blob.c"), str(objs / "my_sphere.so"), ['-DNDT_TEST_PLUGIN_TYPE="sphere"'])
+    (objs / "not_a_plugin.so").write_bytes(b"junk")         # the reference prints dlerror() and goes on (object.c:57-60)
+    scene_so = str(tmp_path / "plug_scene.so")
+    _compile_against_host_api(tmp_path, os.path.join(plug, "plug_scene.c"), scene_so)
+    out = str(tmp_path / "out.ndtscene")
+    base = [driver, "-s", scene_so, "-d", "4", "-f", "0:0", "-o", str(objs), "--dump-scene", out]
+    ok = subprocess.run(base + ["-u", "sphere"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    assert "object type 'sphere' from 'my_sphere.so': built in" in ok.stdout
+    assert "loaded object type 'blob' from 'blob.so'" in ok.stdout
+    assert "sphere 2" in open(out).read() or "sphere" in open(out).read()
+    bad = subprocess.run(base + ["-u", "blob"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert bad.returncode != 0
+    assert "type 'blob' from the plugin 'blob.so'" in (bad.stderr + bad.stdout)
+    # without -o the type does not exist at all: the reference's message and exit (object.c:233-236)
+    (tmp_path / "elsewhere").mkdir()                        # (the default directory is ./objects, like the reference's)
+    none = subprocess.run([driver, "-s", scene_so, "-d", "4", "-f", "0:0", "--dump-scene", out, "-u", "blob"],
+                          capture_output=True, text=True, cwd=str(tmp_path / "elsewhere"))
+    assert none.returncode != 0 and "Unknown object type 'blob'" in none.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_BIN, "..", "objects")), reason="oracle/_ref not built (make -C oracle ref)")
+def test_the_references_own_object_plugins_are_all_built_in(driver, tmp_path):
+    """`-o` pointed at the compiled reference's objects/ directory: every plugin there names a built-in type."""
+    so = os.path.join(REF_BIN, "random.so")
+    out = str(tmp_path / "out.ndtscene")
+    r = subprocess.run([driver, "-s", so, "-d", "4", "-f", "0:0", "-o", os.path.abspath(os.path.join(REF_BIN, "..", "objects")),
+                        "--dump-scene", out], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "host side only" not in r.stdout
+    assert r.stdout.count("built in (device intersector)") >= 9
+    assert open(out).read() == _fixture_text("c3_random4d")
