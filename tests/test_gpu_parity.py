@@ -380,7 +380,8 @@ def test_jittered_samples_statistically_match_the_oracle(gpu, oracle, name):
         assert moved.sum() <= 0.003 * moved.size + 1, (int(moved.sum()), moved.size)
         z = (out - mu)[noisy] / (sd[noisy] * np.sqrt(1.0 + 1.0 / n_seeds))
         frac5 = float((np.abs(z) < 5).mean())
-        print("%s S=%d: %d noisy values, mean z %+.3f, %.2f %% |z|<5, max |z| %.1f" % (name, S, int(noisy.sum()), z.mean(), 100 * frac5, np.abs(z).max()))
+        print("%s S=%d: %d noisy values, mean z %+.3f (|z| clipped at 15; %d beyond), %.2f %% |z|<5, max |z| %.1f" % (
+            name, S, int(noisy.sum()), np.clip(z, -15, 15).mean(), int((np.abs(z) >= 15).sum()), 100 * frac5, np.abs(z).max()))
         # (a pixel of which an edge cuts off a sliver: its ensemble is constant to 1e-5 until a sample lands in the sliver -- one
         # of the device's eleven did in ns_vr_zoo4d's pixel (5, 12), z = -1263 on all three channels.  Such values are
         # counted, at most 5 in a thousand, and clipped in the bias statistic instead of deciding it alone)
