@@ -191,6 +191,38 @@ def test_item_sets_change_nothing(gpu, oracle, name):
         return
     for a, b in zip(kat1, kat0):
         assert np.array_equal(a, b)
+    # 60 000 more rays between random points of the scene's box (closest-hit, directional-shadow and limited queries mixed):
+    # sets against lists, and a slice of them against the oracle
+    rng = np.random.default_rng(99)
+    d = g.scene.dims
+    vecs = np.asarray(g.scene.vecs, dtype=np.float64).ravel()
+    st_ = g.scene.struct
+    lo, hi = vecs[st_.bb_lower_off:st_.bb_lower_off + d], vecs[st_.bb_upper_off:st_.bb_upper_off + d]
+    grow = 0.25 * (hi - lo) + 1.0
+    a_pts = rng.uniform(lo - grow, hi + grow, (60000, d))
+    b_pts = rng.uniform(lo, hi, (60000, d))
+    dirs = b_pts - a_pts
+    dist = np.linalg.norm(dirs, axis=1, keepdims=True)
+    many = np.zeros((60000, 2 * d + 1))
+    many[:, :d] = a_pts
+    many[:, d:2 * d] = dirs / dist
+    many[:, 2 * d] = -1.0
+    many[1::3, 2 * d] = 0.0
+    many[2::3, 2 * d] = dist[2::3, 0] * rng.uniform(0.3, 1.2, dist[2::3, 0].shape)
+    try:
+        gpu.upload_scene(g.scene)
+        with_sets = gpu.trace_rays(many)
+        gpu.set_option("item_sets", 0)
+        gpu.upload_scene(g.scene)
+        with_lists = gpu.trace_rays(many)
+    finally:
+        gpu.set_option("item_sets", 1)
+    for a, b in zip(with_sets, with_lists):
+        assert np.array_equal(a, b)
+    want = oracle.trace(g.scene, many[:3000])
+    assert np.array_equal(with_sets[0][:3000], want[0])
+    assert np.array_equal(with_sets[1][:3000], want[1])
+    assert (with_sets[0] >= 0).mean() > 0.05            # (the rays do meet the scene)
     # every leaf list reversed: another scan order, other answers where it matters (ties, the dist_limit break)
     fs = load_scene(os.path.join(GOLDEN, g.meta["scene_file"]))     # a copy of its own: the cached scene stays as it is
     refs = list(fs.leaf_refs)
