@@ -957,7 +957,17 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
 // The bounce's range comes from the device-side table; the grid is sized for the host's upper
 // bound, workgroups past the end leave at once.  (A grid-stride loop here cost 50 VGPRs and
 // half the occupancy.)
-__global__ void __launch_bounds__(256) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
+// (3-D .. 5-D: 512-lane workgroups.  shade_emit(0) of a frame whose primaries all hit is started at the dispatcher's ~120
+// workgroups per microsecond -- 8 100 of 256 lanes take 68 us to start: hypercube 3-D 0.636 -> 0.617 ms, balls 0.992 -> 0.982.
+// 6-D .. 8-D, 244 registers a lane: slower that way, 2.03 against 1.99 ms and 3.45 against 3.39)
+#ifndef NDT_EMIT_BLOCK
+#if NDT_DIMS <= 5
+#define NDT_EMIT_BLOCK 512
+#else
+#define NDT_EMIT_BLOCK 256
+#endif
+#endif
+__global__ void __launch_bounds__(NDT_EMIT_BLOCK) k_shade_emit(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
 {
     __shared__ EmitShared sh;
     const LevelRange lr = ws.levels[level];
@@ -1144,7 +1154,7 @@ static unsigned shade_grid(long long upper) { return grid_for(upper, 256); }
 static void launch_shade_emit(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper)
 {
     if (upper <= 0) return;
-    hipLaunchKernelGGL(k_shade_emit, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level);
+    hipLaunchKernelGGL(k_shade_emit, dim3(grid_for(upper, NDT_EMIT_BLOCK)), dim3(NDT_EMIT_BLOCK), 0, s, blob, sd, ws, rg, level);
 }
 static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper)
 {
