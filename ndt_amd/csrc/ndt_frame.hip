@@ -2,6 +2,7 @@
 // bounce loop, bottom-up resolve, per-primary colour.  render_image (ndt.c:900) for the deterministic path is one
 // such pass; recursive anti-aliasing and the sampled paths call it once per level / round.
 #include "ndt_ctx.hpp"
+#include "ndt_finish.hpp"
 #include <stddef.h>
 
 void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
@@ -312,65 +313,13 @@ __global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc s
         resolve_node(blob, sd, ws, specular, lr.begin + r);
 }
 
-// get_pixel_color's adaptive loop (ndt.c:488-568) replayed on the one deterministic sample:
-// with samples == 1 the reference re-traces the identical ray k times, k decided by the
-// running-mean test below; the result is (c+...+c)/k and the k-fold ray count.
+// (the pixel itself: ndt_finish.hpp)
 __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
                                                        double *rgba, double *depth_out)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long weighted = 0ull;
-    if (g < rg.n_primary && ws.depth_left[g] > 0) {
-        long long out_idx = g;                          // list mode: one colour per sample
-        if (!rg.samples) {
-            const int tile = (int)(g >> 6), lane = (int)(g & 63);
-            const int px = (tile % rg.tiles_x) * 8 + (lane & 7);
-            const int py = (tile / rg.tiles_x) * 8 + (lane >> 3);
-            out_idx = (long long)py * rg.width + px;    // dbl_image_set_pixel, image.c:126
-        }
-        const double l[4] = { ws.clr[0 * ws.cap + g], ws.clr[1 * ws.cap + g], ws.clr[2 * ws.cap + g],
-                              ws.hit_obj[g] >= 0 ? 1.0 : blob[sd.off_cam + 4 * N_ + 7] };
-        double t[4] = { 0.0, 0.0, 0.0, 0.0 };
-        const double max_diff = 1.0 / 256.0;
-        double clr_diff = 256;
-        int samples = 0;
-        // Every sample is the same colour l, so the reference's
-        //     clr_diff = max_c |t_c/(i-1) - (t_c+l_c)/i|        (t = l+l+...+l, i terms)
-        // is max_c(l_c)/(i(i-1)) up to rounding (relative error < 4 i^2 ulp: a difference of two
-        // quotients of an i-term running sum).  The six divisions are only spent when that
-        // estimate lies inside the error band around 1/256; otherwise the loop-exit decision
-        // is already certain and identical to the exact one.
-        const double gb0 = (fabs(l[1]) > fabs(l[2])) ? fabs(l[1]) : fabs(l[2]);
-        const double lmax = (fabs(l[0]) > gb0) ? fabs(l[0]) : gb0;
-        const bool finite = lmax <= 1.0e300;          // false for inf / nan: always take the exact path
-        for (int i = 0; i < 1 || (!rg.raw_samples && i < 10000 && clr_diff > max_diff); ++i) {
-            if (i > 1) {
-                const double ii = (double)i * (double)(i - 1);
-                const double est = lmax / ii;
-                const double band = 1.0e-15 * (8.0 * (double)i * (double)i) + 1.0e-12;
-                if (finite && est > max_diff * (1.0 + band)) {
-                    clr_diff = est;             // certainly still above the threshold: keep sampling
-                } else if (finite && est < max_diff * (1.0 - band)) {
-                    clr_diff = est;             // certainly converged: the loop ends here
-                } else {
-                    const double dr = fabs(t[0] / (i - 1) - (t[0] + l[0]) / i);
-                    const double dg = fabs(t[1] / (i - 1) - (t[1] + l[1]) / i);
-                    const double db = fabs(t[2] / (i - 1) - (t[2] + l[2]) / i);
-                    const double gb = (dg > db) ? dg : db;      // MAX, image.h:31
-                    clr_diff = (dr > gb) ? dr : gb;
-                }
-            }
-            t[0] += l[0]; t[1] += l[1]; t[2] += l[2]; t[3] += l[3];
-            samples += 1;
-        }
-        double *out = rgba + out_idx * 4;
-        out[0] = t[0] / samples;
-        out[1] = t[1] / samples;
-        out[2] = t[2] / samples;
-        out[3] = t[3] / samples;
-        if (depth_out) depth_out[out_idx] = ws.depth[g];       // ndt.c:753-756
-        weighted = (unsigned long long)samples * (unsigned long long)ws.count[g];
-    }
+    if (g < rg.n_primary && ws.depth_left[g] > 0) weighted = finish_pixel<false>(blob, sd, ws, rg, N_, g, rgba, depth_out);
     // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
     // saturates near 90 atomics/us, and there are 32k wavefronts at 1080p)
     for (int d = 32; d > 0; d >>= 1) weighted += __shfl_down(weighted, d, 64);

@@ -82,14 +82,32 @@ template <int K> NDT_DEV void store_soa(double *base, long long stride, long lon
 // render_pixel (ndt.c:578-653, MONO) + the ray set-up of get_pixel_color (ndt.c:516-549) +
 // camera_target_point's CAMERA_NORMAL branch (camera.c:557-575).
 // Slot g of the pool <-> lane (g % 64) of 8x8 pixel tile (g / 64): one wavefront = one tile.
-__global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg)
+// One primary: render_pixel + the head of get_pixel_color (ndt.c:578-653, 488-550) for grid slot / sample g: the node's
+// record (ray, weight, bounces left) is written, and the ray is returned.  False: a padding slot or a blank line (marked so).
+// COH: agent-scope (write-through) stores -- inside the frame kernel other wavefronts of the same launch read the record.
+template <bool COH> NDT_DEV void prim_sti(int *p, int v)
 {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= rg.n_primary) return;
-    ws.child_refl[g] = -1;
-    ws.child_refr[g] = -1;
-    ws.count[g] = 0;
-    ws.sh_mask[g] = 0ull;
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH> NDT_DEV void prim_st(double *p, double v)
+{
+    if (COH) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH> NDT_DEV void prim_stu(unsigned long long *p, unsigned long long v)
+{
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg, long long g, double (&pos)[N],
+                          double (&look)[N])
+{
+    prim_sti<COH>(ws.child_refl + g, -1);
+    prim_sti<COH>(ws.child_refr + g, -1);
+    prim_sti<COH>(ws.count + g, 0);
+    prim_stu<COH>(ws.sh_mask + g, 0ull);
     double ip, jp;              // image position in pixels (ndt.c:590-592)
     bool live;
     int eye = rg.eye;
@@ -107,9 +125,9 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
         jp = rg.row_pair ? rg.row_begin + (py >> 1) * rg.row_step + (py & 1) : rg.row_begin + py * rg.row_step;
     }
     if (!live) {
-        ws.depth_left[g] = 0;       // padding slot: never traced, never shaded
-        ws.hit_obj[g] = -1;
-        return;
+        prim_sti<COH>(ws.depth_left + g, 0);        // padding slot: never traced, never shaded
+        prim_sti<COH>(ws.hit_obj + g, -1);
+        return false;
     }
     // (jittered samples: the PIXEL decides the half, the jitter comes after -- i + dx/2 and j - dy/2 lie in [i, i+1) and (j-1, j])
     const double half_i = rg.raw_samples ? floor(ip) : ip, half_j = rg.raw_samples ? ceil(jp) : jp;
@@ -129,14 +147,14 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
             jp = jp - (1080 + 45);
             eye = 2;
         } else {
-            ws.depth_left[g] = 0;   // blank line: black, written by the host's fill
-            ws.hit_obj[g] = -1;
-            return;
+            prim_sti<COH>(ws.depth_left + g, 0);    // blank line: black, written by the host's fill
+            prim_sti<COH>(ws.hit_obj + g, -1);
+            return false;
         }
     }
     const double x = ip / (double)rg.img_w - 0.5;               // ndt.c:632
     const double y = -(jp / y_div - 0.5);                       // ndt.c:633 (629 for HIDEF_3D)
-    double pos[N], pixel[N], temp[N], look[N], cam[N];
+    double pixel[N], temp[N], cam[N];
     blob_vec<N>(blob, sd.off_cam, pos);
     const double focal = blob[sd.off_cam + 4 * N];
     const int ext = sd.off_cam + 4 * N + 8;                     // type, hFov, vFov, leftEye, rightEye, localX, localY, localZ
@@ -226,12 +244,29 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
     v_sub<N>(pixel, cam, look);
     v_unitize<N>(look);
     v_copy<N>(pos, cam);
-    store_soa<N>(ws.ray_o, ws.cap, g, pos);
-    store_soa<N>(ws.ray_v, ws.cap, g, look);
-    ws.frac[g] = 1.0;
-    ws.depth_left[g] = rg.max_depth;
-    if (rg.samples && rg.sample_keys) ws.rng_key[g] = rg.sample_keys[g];
+    {
+        // (store_soa's layout: 64 slots x N components per batch)
+        const long long at = (g >> 6) * (long long)(N * 64) + (g & 63);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            prim_st<COH>(ws.ray_o + at + c * 64, pos[c]);
+            prim_st<COH>(ws.ray_v + at + c * 64, look[c]);
+        }
+    }
+    prim_st<COH>(ws.frac + g, 1.0);
+    prim_sti<COH>(ws.depth_left + g, rg.max_depth);
+    if (rg.samples && rg.sample_keys) prim_stu<COH>(ws.rng_key + g, rg.sample_keys[g]);
+    return true;
 }
+
+__global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rg.n_primary) return;
+    double pos[N], look[N];
+    (void)primary_node<false>(blob, sd, ws, rg, g, pos, look);
+}
+
 
 // ------------------------------------------------------------------ trace
 
