@@ -277,6 +277,8 @@ int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_rend
  *   "hybrid_level"    hybrid: the bounce from which on the frame kernel renders (default 2)
  *   "stream_below"    auto: passes of up to this many primaries go to the streaming frame kernel
  *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
+ *   "stream_fused"            0: the frame kernel between a k_primary and a k_finish_pixels launch instead of making its
+ *                                primaries and writing its pixels itself (tests prove it neutral)
  *   "item_sets"               0: upload a scene of up to 64 items with plain leaf lists (the kernels that read the lists,
  *                                as for larger scenes) instead of 64-bit item sets per leaf (tests prove it neutral)
  *   "shade_pair"      0: lighting of a bounce and shading of the next as two launches

@@ -81,6 +81,7 @@ struct ndt_hip_ctx {
     // ndt_hip_set_option / NDT_HIP_* at context creation (include/ndt_hip.h)
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
+    bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
     int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;

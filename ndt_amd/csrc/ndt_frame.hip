@@ -469,6 +469,10 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             sa.roots_are_primaries = 1;
             sa.valid_begin = 0;
             sa.valid_end = rg.n_primary;
+            // the kernel makes its own primaries and writes its own pixels (option stream_fused, on by default)
+            sa.fused = ctx->stream_fused ? 1 : 0;
+            sa.rgba = (double *)d_rgba;
+            sa.depth_out = (double *)d_depth;
             unsigned int *wave_log = sa.wave_log;
             if (!prof) sa.wave_log = nullptr;
             else if (wave_log) HIP_TRY(hipMemsetAsync(wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
@@ -485,10 +489,11 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 hipExtLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, sa, node_batches, sh_batches, 1);
             else
                 hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, node_batches, sh_batches, 1);
-            kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+            if (!sa.fused) kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
             kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
-            hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
-                               rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+            if (!sa.fused)
+                hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                                   rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
             if (prof)
                 hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
             else
@@ -704,6 +709,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 sa.valid_begin = (int)roots.begin;
                 sa.valid_end = (int)(roots.begin + roots.count);
                 sa.roots_are_primaries = 0;
+                sa.fused = 0;
                 if (!prof) sa.wave_log = nullptr;
                 else if (sa.wave_log) HIP_TRY(hipMemsetAsync(sa.wave_log, 0, (size_t)24 * NDT_STREAM_LOG_WAVES * sizeof(unsigned int), s));
                 if ((long long)sa.root_begin + sa.n_primary > ws.cap) {

@@ -171,6 +171,11 @@ struct StreamArgs {
     int valid_begin, valid_end;
     int node_batches;       // cap / 64: entries per shard of sec_ring
     unsigned int *wave_log; // NDT_HIP_STREAM_PROBE: 16 words per wavefront (what it did and when), else nullptr
+    // fused (a whole frame, roots = primaries): the kernel makes its primaries itself (what k_primary does: a root batch's rays
+    // are computed by the wavefront that traces them) and writes a pixel the moment its ray tree is resolved (what
+    // k_finish_pixels does): two launches and their fill / drain less around the frame kernel
+    int fused;
+    double *rgba, *depth_out;
 };
 #define NDT_STREAM_LOG_WAVES 16384
 

@@ -34,6 +34,8 @@
 // atomic (or a value derived from it) handed them.  Plain stores are used only for what later KERNELS read (the
 // resolved colours of the primaries, depth maps).
 
+#include "ndt_finish.hpp"
+
 // ------------------------------------------------------------------ coherent loads / stores, drained publishes
 
 #ifdef NDT_STREAM_PLAIN   /* experiment only: what the coherent accesses cost (results may be stale) */
@@ -162,6 +164,11 @@ NDT_DEV bool ring_pop(int *head, const int *ring, int &ticket, int &id)
     return id >= 0;
 }
 
+struct WaveStats {          // what a wavefront adds to the frame's statistics when it leaves (not per item: hot words)
+    int children, shadow, max_level;
+    unsigned long long ref;     // fused: the reference-equivalent rays of the pixels this wavefront finished (all lanes: summed at the end)
+};
+
 // ------------------------------------------------------------------ the ray tree, bottom-up
 
 // get_ray_color's blend of a node's own colour with what its children returned (ndt.c:402-429): resolve_node of
@@ -205,9 +212,10 @@ NDT_DEV void stream_resolve(const double *mat, const SceneDesc &sd, const Worksp
 // Lanes with `active` report to node `cur` that one of the things it waits for is done (its own lighting, or a child
 // whose colour is final).  The lane that brings the count to zero blends the node and reports to ITS parent, and so on
 // up to the primary.  The caller has drained the stores that made its contribution final.  (Every lane calls.)
-NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace &ws, const StreamArgs &sa, int specular, int cur,
-                         bool active)
+NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace &ws, const StreamArgs &sa, const RenderGeom &rg, int cur,
+                         bool active, WaveStats &stats)
 {
+    const int specular = rg.specular;
     while (__ballot(active) != 0ull) {
         if (active) {
             const int old = atomicSub(sa.pend + cur, 1);
@@ -216,7 +224,11 @@ NDT_DEV void complete_up(const double *mat, const SceneDesc &sd, const Workspace
             } else {
                 stream_resolve(mat, sd, ws, specular, cur);
                 if (cur < sa.root_begin + sa.n_primary) {
-                    active = false;                 // a root of the forest (a primary: k_finish_pixels takes it from here)
+                    active = false;                 // a root of the forest: a primary.  Its pixel: here (fused), or k_finish_pixels
+                    if (sa.fused) {
+                        drain();                    // (the colour just blended is read back through L2)
+                        stats.ref += finish_pixel<true>(mat, sd, ws, rg, N, cur, sa.rgba, sa.depth_out);
+                    }
                 } else {
                     cur = cldi(sa.parent + cur);
                 }
@@ -330,19 +342,17 @@ NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const Sce
 // and normal, background colour, children, shadow rays -- shade_emit_node with per-wavefront reservations (the
 // wavefronts of a persistent launch are not in step, so there is no workgroup to share a reservation with; they also
 // do not all arrive at the counters at once).  Every lane of the wavefront calls.
-struct WaveStats {          // what a wavefront adds to the frame's statistics when it leaves (not per item: hot words)
-    int children, shadow, max_level;
-};
 
 NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
                                 const StreamArgs &sa, int nb, bool valid, int depth_left, const double (&src)[N],
                                 const double (&look)[N], int obj, int prim, WaveStats &stats, int home, int &up_node, bool &up_active,
-                                bool &light_now, bool &any_shaded)
+                                bool &light_now, bool &any_shaded, bool &final_root)
 {
     up_node = 0;
     up_active = false;
     light_now = false;
     any_shaded = false;
+    final_root = false;
     StreamCtl *ctl = sa.ctl;
     const int lane = __lane_id();
     const long long g = (long long)nb * 64 + lane;
@@ -354,9 +364,9 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
             isect_full(blob, &sd, prim, src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
-            if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;     // ndt.c:366-370
+            if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) cst(ws.depth + g, shaded ? 1.0 / trace_dist : 0.0);     // ndt.c:366-370
         } else if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) {
-            ws.depth[g] = 0.0;                                              // ndt.c:372-373
+            cst(ws.depth + g, 0.0);                                         // ndt.c:372-373
         }
         if (shaded) {
             cstore_soa<N>(ws.hit_p, g, hit);
@@ -552,8 +562,10 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
     } else {
         drain();
     }
-    // ---- nodes that are final already (background): their parents hear of it (the caller's complete_up)
+    // ---- nodes that are final already (background): their parents hear of it (the caller's complete_up); a root's pixel
+    // can be written (fused)
     up_active = valid && !shaded && g >= sa.root_begin + sa.n_primary;
+    final_root = valid && !shaded && g < sa.root_begin + sa.n_primary;
     if (up_active) up_node = cldi(sa.parent + g);
     // ---- the batch's lighting: later (when its shadow rays are answered), now (it has none), or never (nothing was hit)
     any_shaded = live;
@@ -686,7 +698,7 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
     unsigned int pr_pop = 0, pr_load = 0, pr_trace = 0;         // of the node and shadow items: looking for work, loading rays, trace_kd
     unsigned int pr_trace_sh = 0, pr_up = 0;                    // trace_kd of the shadow items alone; complete_up + counters
     unsigned long long pr_mark = 0, pr_top = 0;
-    WaveStats stats = { 0, 0, 0 };
+    WaveStats stats = { 0, 0, 0, 0ull };
     int items = 0;
     int light_next = -1;            // a node batch this wavefront shaded that has no shadow rays to wait for: lit next
     while (true) {
@@ -744,16 +756,22 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
             } else {
                 slot = (long long)id * 64 + lane;
             }
-            const int tag = is_shadow ? cldi(sa.sowner + slot) : cldi(ws.depth_left + slot);     // owner node / bounces left
+            // fused: a root batch's primaries are made here (k_primary's work), not read
+            const bool make = sa.fused != 0 && !is_shadow && slot < sa.root_begin + sa.n_primary;        // (wave-uniform)
+            double o[N], v[N];
+            int tag;
+            if (make) tag = primary_node<true>(gblob, sd, ws, rg, slot, o, v) ? rg.max_depth : 0;
+            else tag = is_shadow ? cldi(sa.sowner + slot) : cldi(ws.depth_left + slot);                  // owner node / bounces left
             // (a slot of a root batch outside the roots' range is not this launch's node)
             const bool valid = is_shadow ? tag >= 0
                                          : tag > 0 && (slot >= sa.root_begin + sa.n_primary || (slot >= sa.valid_begin && slot < sa.valid_end));
-            double o[N], v[N];
             double lim = -1.0;
             int obj = -1, prim = -1;
             if (valid) {
-                cload_soa<N>(is_shadow ? ws.so : ws.ray_o, slot, o);
-                cload_soa<N>(is_shadow ? ws.sv : ws.ray_v, slot, v);
+                if (!make) {
+                    cload_soa<N>(is_shadow ? ws.so : ws.ray_o, slot, o);
+                    cload_soa<N>(is_shadow ? ws.sv : ws.ray_v, slot, v);
+                }
                 if (is_shadow) lim = cld(ws.slim + slot);
                 unsigned long long pr_a = 0;
                 if (sa.wave_log) {
@@ -800,9 +818,10 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                     if (old == run) ring_push(&ctl->fin_tail.v, sa.fin_ring, nb);
                 }
             } else {
-                bool light_now, any_shaded;
+                bool light_now, any_shaded, final_root;
                 stream_shade_batch(blob, gblob, sd, ws, rg, sa, id, valid, tag, o, v, obj, prim, stats, home, up_node, up_active, light_now,
-                                   any_shaded);
+                                   any_shaded, final_root);
+                if (sa.fused && final_root) stats.ref += finish_pixel<true>(gblob, sd, ws, rg, N, slot, sa.rgba, sa.depth_out);
                 parts_done = any_shaded ? 1 : 2;        // nothing hit: no lighting to wait for
                 if (light_now) light_next = id;
             }
@@ -815,7 +834,7 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
         if (kind == 1 || kind == 3) {
             unsigned long long pr_b = 0;
             if (sa.wave_log) pr_b = wall_clock64();
-            complete_up(gblob, sd, ws, sa, rg.specular, up_node, up_active);
+            complete_up(gblob, sd, ws, sa, rg, up_node, up_active, stats);
             if (sa.wave_log) pr_up += (unsigned int)(wall_clock64() - pr_b);
             if (lane == 0) atomicSub(&ctl->outstanding[id % NDT_PRIM_SHARDS].v, 64 * parts_done);
         }
@@ -858,6 +877,11 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                 break;
             }
         }
+    }
+    if (sa.fused) {
+        unsigned long long ref = stats.ref;
+        for (int d = 32; d > 0; d >>= 1) ref += __shfl_xor(ref, d, 64);
+        if (lane == 0 && ref) atomicAdd(ws.ref_rays + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63), ref);
     }
     if (lane == 0) {
         if (stats.children) atomicAdd(&ctl->n_children.v, stats.children);

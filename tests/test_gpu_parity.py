@@ -153,12 +153,15 @@ def test_every_pipeline_renders_the_same_frame(gpu, name):
     gpu.upload_scene(g.scene)
     outs = []
     try:
-        for pipeline in (1, 2, 3):
+        for pipeline, fused in ((1, 1), (2, 1), (2, 0), (3, 1)):
+            # (stream_fused 0: the frame kernel between k_primary and k_finish_pixels instead of doing their work itself)
             gpu.set_option("pipeline", pipeline)
+            gpu.set_option("stream_fused", fused)
             img, st = gpu.render(g.width, g.height, g.depth)
             outs.append((img, (st.rays_primary, st.rays_secondary, st.rays_shadow, st.rays_ref_equiv, st.levels)))
     finally:
         gpu.set_option("pipeline", 0)
+        gpu.set_option("stream_fused", 1)
     for img, counts in outs[1:]:
         assert np.array_equal(img, outs[0][0])
         assert counts == outs[0][1]
