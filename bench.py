@@ -328,7 +328,11 @@ def main():
             # read once, the framebuffer read-modify-write) of the rays one launch of the dominant kernel traces, over
             # that kernel's average duration.  The bytes of B_ray are moved by ALL kernels of the frame, the time is one
             # kernel's: `frac_frame` divides by the whole frame instead, and `measured` is what the counters saw.
+            # `bound` is the roofline the contract prices the path against (BASELINE.json: HBM, 8 TB/s); `bound_that_holds` is
+            # what the counters say limits the kernel -- it is NOT HBM-bound (measured traffic: single-digit % of peak, see
+            # `measured`): FP64 vector issue and the latency of a divergent traversal (`secondary`)
             "bound": "hbm",
+            "bound_that_holds": "fp64_valu_issue_and_latency",
             "kernel": "k_frame_stream (the whole ray tree in one persistent launch)" if stream else "k_trace (trace_kd, one ray per lane)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -125,7 +125,8 @@ typedef struct ndt_flat_scene {
     const int32_t *obj_refs; int64_t n_obj_refs;
 
     /* camera after camera_aim (camera.c:132), before render_image's dirX *= W/H (ndt.c:926);
-     * offsets into vecs.  Only CAMERA_NORMAL (camera.c:557-575) is on the device path. */
+     * offsets into vecs.  cam_type: 0 CAMERA_NORMAL (camera.c:557-575), 1 CAMERA_VR, 2 CAMERA_PANO (camera.c:506-555; they
+     * need the ABI 2 fields below: fields of view, local axes). */
     int32_t cam_type;
     int32_t cam_pos_off, cam_img_orig_off, cam_dir_x_off, cam_dir_y_off;
     double  cam_focal_distance;
@@ -260,7 +261,7 @@ int ndt_hip_render_rgba8(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *
  * MPI_MODE_ROW (ndt.c:812-820: row_start = rank, row_step = size): context k renders rows
  * p->row_begin + (k + i*n_ctx)*p->row_step.  Every context must hold the same uploaded scene.  Each device pushes
  * its finished rows straight into the assembled image on ctxs[0]'s device (peer stores over xGMI; through a staging
- * copy where peer access is unavailable) -- the reference instead sum-reduces full-size zero-padded images up a
+ * copy where peer access is unavailable or option "multi_path" asks for it) -- the reference instead sum-reduces full-size zero-padded images up a
  * binary tree (mpi_collect_image, ndt.c:1277-1309).  `format` = ndt_image_format.  _device: `d_out` is memory of
  * ctxs[0]'s device; plain: `out` is host memory.  stats: ray counts summed over the contexts, times = the slowest's.
  * Not with a depth map.  Returns when the image is complete. */
@@ -268,6 +269,13 @@ int ndt_hip_render_multi_device(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const n
                                 void *d_out, ndt_render_stats *stats);
 int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_render_params *p, int32_t format,
                          void *out, ndt_render_stats *stats);
+
+/* How a context's rows reached the assembled image in the last ndt_hip_render_multi[_device] call it took part in, so
+ * that a multi-GPU run can be diagnosed from its log (option "multi_path" chooses; `ndt_hip -g N` prints it):
+ * LOCAL = the context lives on ctxs[0]'s device; PEER = its push kernel stored over xGMI into ctxs[0]'s HBM;
+ * STAGED = one hipMemcpyPeerAsync into a staging buffer on ctxs[0]'s device, pushed from there; NONE = no rows. */
+enum ndt_multi_path { NDT_MULTI_NONE = 0, NDT_MULTI_LOCAL = 1, NDT_MULTI_PEER = 2, NDT_MULTI_STAGED = 3 };
+int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
 
 /* Switches of a context.  None changes an image; they choose between equivalent ways of producing it, or turn diagnostics
  * on.  The same names, upper-cased behind NDT_HIP_ (NDT_HIP_PIPELINE, NDT_HIP_DEBUG_LEVELS ...), are read from the
@@ -281,6 +289,11 @@ int ndt_hip_render_multi(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_rend
  *                                primaries and writing its pixels itself (tests prove it neutral)
  *   "item_sets"               0: upload a scene of up to 64 items with plain leaf lists (the kernels that read the lists,
  *                                as for larger scenes) instead of 64-bit item sets per leaf (tests prove it neutral)
+ *   "leaf_history"            scenes in the global-memory tier (more than 256 items): a ray remembers what it visited as up to
+ *                                this many {leaf, cut} pairs (default and maximum 4) before it falls back to its bit mask in
+ *                                the slab; 0: the slab only (tests prove every value neutral)
+ *   "multi_path"      ndt_hip_render_multi: 0 auto (stores on the same device, peer stores over xGMI, a staged copy where
+ *                     there is no peer access), 1 never staged, 2 always staged -- also between contexts of one device
  *   "shade_pair"      0: lighting of a bounce and shading of the next as two launches
  *   "debug_levels"    profiled renders print the bounces and the duration of every trace launch
  *   "exit_probe" / "shade_probe" / "stream_probe"   profiled renders log the life of every wavefront of the trace

@@ -450,7 +450,7 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     std::vector<int> new_index((size_t)(fs->n_kd_nodes > 0 ? fs->n_kd_nodes : 1), -1);
     for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
     sd.n_kd_nodes = (int)order.size();
-    std::vector<int> leaf_list;
+    std::vector<int> leaf_list, leaf_first, leaf_num;
     sd.off_kd = b.words();
     for (size_t i = 0; i < order.size(); ++i) {
         const ndt_flat_kdnode &k = fs->kd_nodes[order[i]];
@@ -459,7 +459,9 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             b.push_ints(k.dim, new_index[k.right]);
             b.push(k.boundary);
         } else {
-            b.push_ints(-1, 0);
+            b.push_ints(-1, (int)leaf_first.size());       // a leaf's ordinal (VisitMask<0>, leaf history)
+            leaf_first.push_back((int)leaf_list.size());
+            leaf_num.push_back(k.num);
             b.push_ints((int)leaf_list.size(), k.num);
             for (int j = 0; j < k.num; ++j) leaf_list.push_back(fs->leaf_refs[k.first + j]);
         }
@@ -755,11 +757,37 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         ctx->have_eyes = offs[0] >= 0 && offs[1] >= 0;
         ctx->have_local_axes = offs[2] >= 0 && offs[3] >= 0 && offs[4] >= 0;
     }
-    sd.total_words = b.words();
-
     // tier 0: trace sections fit the LDS budget and the visit mask fits registers
     const bool fits_lds = (size_t)sd.trace_words * sizeof(double) <= NDT_TRACE_LDS_LIMIT;
     ctx->tier = (fits_lds && sd.mask_words <= NDT_MASK_REG_WORDS) ? 0 : 1;
+    // Leaf history (ndt_device.hpp:VisitMask<0>): the items of every leaf as a bit set + every leaf's list range, when
+    // every leaf list ascends in item number (a scan that stopped after item `last` then visited the leaf's items <= last)
+    sd.off_lset = sd.off_lrange = 0;
+    sd.hist_cap = ctx->leaf_history > 4 ? 4 : ctx->leaf_history;
+    if (ctx->tier == 1 && ctx->leaf_history > 0 && fs->n_items < 65535 && leaf_first.size() < 65536 && !leaf_first.empty()) {
+        bool ascending = true;
+        for (size_t l = 0; l < leaf_first.size() && ascending; ++l)
+            for (int j = 0; j < leaf_num[l]; ++j) {
+                const int id = leaf_list[(size_t)leaf_first[l] + j];
+                if (id < 0 || id >= fs->n_items || (j > 0 && id <= leaf_list[(size_t)leaf_first[l] + j - 1])) ascending = false;
+            }
+        if (ascending) {
+            sd.off_lset = b.words();
+            std::vector<unsigned long long> set((size_t)sd.mask_words);
+            for (size_t l = 0; l < leaf_first.size(); ++l) {
+                std::fill(set.begin(), set.end(), 0ull);
+                for (int j = 0; j < leaf_num[l]; ++j) {
+                    const int id = leaf_list[(size_t)leaf_first[l] + j];
+                    set[(size_t)id >> 6] |= 1ull << (id & 63);
+                }
+                for (unsigned long long x : set) b.push_ints((int)(x & 0xffffffffull), (int)(x >> 32));
+            }
+            sd.off_lrange = b.words();
+            for (size_t l = 0; l < leaf_first.size(); ++l) b.push_ints(leaf_first[l], leaf_num[l]);
+        }
+    }
+    sd.total_words = b.words();
+
     if (ctx->tier == 0 && sd.mask_words == 1) {
         if (item_sets) {
             for (int i = 0; i < fs->n_inf; ++i) sd.inf_bits |= 1ull << fs->inf_refs[i];

@@ -59,6 +59,7 @@ struct ndt_hip_ctx {
     // workspace
     Workspace ws{};
     std::vector<void *> ws_allocs;
+    std::vector<void *> sa_allocs;                  // the frame kernel's queues and counters (ensure_stream_args)
     std::vector<std::pair<void *, size_t>> pool;    // scratch of the multi-pass renderers (AaBuffers)
     long long ws_dims = 0;
     long long ws_slab_words = 0;
@@ -83,6 +84,7 @@ struct ndt_hip_ctx {
     bool hull_box = true, face_box = true, shade_pair = true;
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
+    int leaf_history = 4;           // global-memory tier: visited = {leaf, cut} pairs per ray (VisitMask<0>); 0: the slab only; 1 .. 3: fewer pairs (tests)
     int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;
     int sa_nseg = 0;
@@ -92,6 +94,13 @@ struct ndt_hip_ctx {
     size_t d_shard_bytes = 0;
     void *d_image = nullptr;        // ndt_hip_render_multi (host output): the assembled frame on the first context's device
     size_t d_image_bytes = 0;
+    // ndt_hip_render_multi without peer stores: this context's staging buffer and stream ON THE FIRST CONTEXT'S DEVICE
+    void *d_stage = nullptr;
+    size_t d_stage_bytes = 0;
+    hipStream_t stage_stream = nullptr;
+    int stage_device = 0;
+    int multi_path = 0;             // option "multi_path": 0 auto, 1 never staged, 2 always staged
+    int multi_path_taken = 0;       // ndt_multi_path of the last multi-context frame (ndt_hip_multi_path_taken)
     ndt_impl::CtxWorker *worker = nullptr;
     int *h_counters = nullptr;      // pinned
     LevelRange *h_levels = nullptr; // pinned, NDT_MAX_LEVELS + 1
@@ -127,6 +136,7 @@ void add_stats(ndt_render_stats &acc, const ndt_render_stats &st);
 
 // ndt_multi.hip
 void worker_stop(ndt_hip_ctx *ctx);
+void free_stage(ndt_hip_ctx *ctx);
 
 // ndt_aa.hip / ndt_sampled.hip
 int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);

@@ -26,7 +26,7 @@
 #define NDT_F_INF_ENDS    0x200     /* cylinder.c:87 / hcylinder.c:107 */
 #define NDT_F_USE_NORMALS 0x400     /* hfacet.c:283 */
 #define NDT_F_TRANSPARENT 0x800
-#define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_host.hip:hcube_hull_box) */
+#define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_blob.hip:hcube_hull_box) */
 #define NDT_F_FACEBOX     0x2000    /* ... followed by the mask of possible faces and every face's own box in that frame */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
@@ -57,6 +57,10 @@ struct SceneDesc {
     // instead of {first, num}, and the infinite list is this mask (trace_kd, "item sets")
     unsigned long long inf_bits;
     int off_nset;      // ... and one word per kd node: the set of the items of all leaves below it (a leaf: its own items)
+    // global-memory tier with ascending leaf lists (VisitMask<0>, "leaf history"): a kd leaf's record names its ordinal
+    // (high half of word 0); per leaf, mask_words words = its items as a bit set, and one word {first, num} = its list
+    int off_lset, off_lrange;      // off_lset == 0: no history, visit masks live in the slab
+    int hist_cap;                  // history entries per ray (4; tests: 1 .. 3 force the replay into the slab)
 };
 
 // ------------------------------------------------------------------ random streams
@@ -291,33 +295,28 @@ template <int N>
 NDT_DEV void axes_quadratic(const double *blob, int p0, int rec, int m, const double (&o)[N], const double (&v)[N],
                             double &qa, double &qb, double &qc)
 {
-    // hcylinder.c:159-185 / orthotope.c:175-199
-    double sA[N], sum_A[N], P[N], Q[N], pos[N];
-    v_zero<N>(sum_A);
-    for (int i = 0; i < m; ++i) {
-        int a = rec + i * (N + 3);
-        double ax[N];
-        blob_vec<N>(blob, a, ax);
-        double AdA = blob[a + N + 1];
-        double VdA = v_dot<N>(v, ax);
-        v_scale<N>(ax, VdA / AdA, sA);
-        v_add<N>(sum_A, sA, sum_A);
-    }
-    v_sub<N>(sum_A, v, P);
-    v_zero<N>(sum_A);
+    // hcylinder.c:159-185 / orthotope.c:175-199.  The reference walks the axes twice (P, then Q); here one walk feeds both
+    // sums -- every sum still adds the same terms in the same order -- so an axis record is read once.
+    double sA[N], sum_P[N], sum_Q[N], P[N], Q[N], pos[N];
+    v_zero<N>(sum_P);
+    v_zero<N>(sum_Q);
     for (int i = 0; i < m; ++i) {
         int a = rec + i * (N + 3);
         double ax[N];
         blob_vec<N>(blob, a, ax);
         double AdA = blob[a + N + 1];
         double BdA = blob[a + N + 2];
+        double VdA = v_dot<N>(v, ax);
+        v_scale<N>(ax, VdA / AdA, sA);
+        v_add<N>(sum_P, sA, sum_P);
         double OdA = v_dot<N>(o, ax);
         v_scale<N>(ax, (OdA - BdA) / AdA, sA);
-        v_add<N>(sum_A, sA, sum_A);
+        v_add<N>(sum_Q, sA, sum_Q);
     }
+    v_sub<N>(sum_P, v, P);
     blob_vec<N>(blob, p0, pos);
     v_sub<N>(pos, o, Q);
-    v_add<N>(Q, sum_A, Q);
+    v_add<N>(Q, sum_Q, Q);
     qa = v_dot<N>(P, P);
     qb = v_dot<N>(P, Q);
     qb *= 2;
@@ -667,7 +666,7 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
 }
 
 // Ray (t >= 0) against the hull box of an hcube: N slabs { axis[N], centre, half extent }.
-// A miss proves that no face of the hcube can be hit (see ndt_host.hip:hcube_hull_box for the
+// A miss proves that no face of the hcube can be hit (see ndt_blob.hip:hcube_hull_box for the
 // margin argument), so the face scan is skipped; a pass decides nothing.
 // The hull box test plus, for hcubes that carry them (NDT_F_FACEBOX), the same test against every face's own
 // box: returns 0 when the ray misses the hull box or every face box (skip the hcube), -1 when all faces are to be
@@ -730,35 +729,91 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
 
 // Per-ray visit mask (the reference callocs obj_num bytes per ray, kd-tree.c:600).
 // MW > 0: MW 64-bit words in registers, indexed by unrolled selects.
-// MW == 0: `ext` points at this lane's words in a global scratch slab (large scenes).
+// MW == 0 (large scenes: the 6-D .. 8-D hypercubes, 728 .. 6560 items), two representations of the same set:
+//   leaf history  What a ray has visited is "the items of the leaves it has scanned, up to where each scan ended".  Leaf
+//                 lists ascend in item number (the reference's kd builder keeps the scene's object order in every leaf;
+//                 checked at upload), so a scan that ended after item `last` visited exactly the leaf's items with a
+//                 number <= last.  The ray keeps up to four {leaf, last + 1} pairs in registers; the blob carries every
+//                 leaf's items as a bit set (read-only, a few hundred KB: cache resident); "was item x visited" = for
+//                 some pair, bit x of the leaf's set and x < cut.  No stores, no per-ray memory: the scan of a ray's first
+//                 leaf -- most of all scanning -- touches nothing but the scene.
+//   slab          `ext` points at this lane's words in a global slab (one bit per item, as the reference's byte per
+//                 item).  432 MB for the resident wavefronts of the 8-D scene: every test-and-set is a read-modify-write
+//                 that misses every cache, two dependent memory round trips per scanned item -- what the trace kernel of
+//                 this tier used to wait for.  Now the fallback: a ray that finishes a fifth leaf replays its history into
+//                 the slab (`spill`) and goes on there; scenes whose lists do not ascend never leave it.
+struct LeafSets {
+    const unsigned long long *sets;     // [leaf][words]: the items of every kd leaf as a bit set (nullptr: no history)
+    const double *blob;                 // for the replay: leaf ranges and lists
+    int words, off_lrange, off_leaf;
+    int cap;                            // history entries a ray may hold (1 .. 4; tests shrink it to force the replay)
+};
 template <int MW> struct VisitMask {
     unsigned long long w[MW > 0 ? MW : 1];
     unsigned long long *ext;
     int ext_stride;
-    // MW == 0, masks of up to 128 words (8192 items): which words of the slab this ray has written.  A word that has
+    // slab, masks of up to 128 words (8192 items): which words of the slab this ray has written.  A word that has
     // not been written yet counts as zero, so a new ray costs two register moves instead of `words` stores to the slab
     // (103 words = 0.8 KB per ray on the 8-D hypercube: more than the whole algorithmic ray record).
-    unsigned long long live0, live1;
-    bool lazy;
+    // leaf history: entry = leaf << 16 | cut (items of `leaf` with a number < cut are visited); hist_n < 0: the ray is on the slab.
+    // (h0 .. h3 and the slab's live0 / live1 are never needed together: one set of registers)
+    LeafSets ls;
+    unsigned int h0, h1, h2, h3;
+    int hist_n;
+    int slab_words;
+    NDT_DEV bool lazy() const { return slab_words <= 128; }
     NDT_DEV void clear(int words)
     {
         if (MW > 0) {
 #pragma unroll
             for (int i = 0; i < MW; ++i) w[i] = 0ull;
         } else {
-            lazy = words <= 128;
-            live0 = 0ull;
-            live1 = 0ull;
-            if (!lazy)
-                for (int i = 0; i < words; ++i) ext[(size_t)i * ext_stride] = 0ull;
+            slab_words = words;
+            hist_n = 0;
+            h0 = h1 = h2 = h3 = 0u;
+            if (!ls.sets) begin_slab();
         }
     }
-    // returns true when `id` was already visited; marks it otherwise
-    NDT_DEV bool test_and_set(int id)
+    NDT_DEV void begin_slab()
+    {
+        hist_n = -1;
+        h0 = h1 = h2 = h3 = 0u;         // = live0, live1
+        if (!lazy())
+            for (int i = 0; i < slab_words; ++i) ext[(size_t)i * ext_stride] = 0ull;
+    }
+    NDT_DEV bool slab_test_and_set(int id)
     {
         const unsigned long long bit = 1ull << (id & 63);
         const int word = id >> 6;
+        bool written = true;
+        if (lazy()) {
+            // live0 = {h1, h0}, live1 = {h3, h2}: one bit per slab word this ray has written
+            const unsigned int wb = 1u << (word & 31);
+            const int q = word >> 5;
+            written = (((q == 0) ? h0 : (q == 1) ? h1 : (q == 2) ? h2 : h3) & wb) != 0u;
+            if (q == 0) h0 |= wb;
+            else if (q == 1) h1 |= wb;
+            else if (q == 2) h2 |= wb;
+            else h3 |= wb;
+        }
+        unsigned long long cur = 0ull;
+        if (written) cur = ext[(size_t)word * ext_stride];
+        if (cur & bit) return true;
+        ext[(size_t)word * ext_stride] = cur | bit;
+        return false;
+    }
+    NDT_DEV bool in_history(unsigned int h, int id) const
+    {
+        const unsigned long long set = ls.sets[(size_t)(h >> 16) * ls.words + (id >> 6)];
+        return ((set >> (id & 63)) & 1ull) != 0ull && (unsigned int)id < (h & 0xffffu);
+    }
+    // returns true when `id` was already visited; marks it otherwise (history: the mark is the leaf's entry, made by
+    // end_leaf when the scan is over -- a list names an item once, so nothing in between asks for it)
+    NDT_DEV bool test_and_set(int id)
+    {
         if (MW > 0) {
+            const unsigned long long bit = 1ull << (id & 63);
+            const int word = id >> 6;
             bool seen = false;
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
@@ -769,19 +824,51 @@ template <int MW> struct VisitMask {
             }
             return seen;
         } else {
-            bool written = true;
-            if (lazy) {
-                const unsigned long long wb = 1ull << (word & 63);
-                written = (((word < 64) ? live0 : live1) & wb) != 0ull;
-                if (word < 64) live0 |= wb;
-                else live1 |= wb;
-            }
-            unsigned long long cur = 0ull;
-            if (written) cur = ext[(size_t)word * ext_stride];
-            if (cur & bit) return true;
-            ext[(size_t)word * ext_stride] = cur | bit;
-            return false;
+            if (hist_n < 0) return slab_test_and_set(id);
+            bool seen = false;
+            if (hist_n > 0) seen = in_history(h0, id);
+            if (hist_n > 1) seen = seen || in_history(h1, id);
+            if (hist_n > 2) seen = seen || in_history(h2, id);
+            if (hist_n > 3) seen = seen || in_history(h3, id);
+            return seen;
         }
+    }
+    // the scan of kd leaf `leaf` is over; `last` = the last item it looked at (-1: none)
+    NDT_DEV void end_leaf(int leaf, int last)
+    {
+        if (MW > 0 || hist_n < 0 || last < 0) return;
+        if (hist_n >= ls.cap) spill();
+        if (hist_n < 0) {
+            spill_leaf((unsigned int)leaf << 16 | (unsigned int)(last + 1));
+            return;
+        }
+        const unsigned int e = (unsigned int)leaf << 16 | (unsigned int)(last + 1);
+        if (hist_n == 0) h0 = e;
+        else if (hist_n == 1) h1 = e;
+        else if (hist_n == 2) h2 = e;
+        else h3 = e;
+        ++hist_n;
+    }
+    NDT_DEV void spill_leaf(unsigned int h)
+    {
+        const int cut = (int)(h & 0xffffu);
+        const int first = blob_int(ls.blob, ls.off_lrange + (int)(h >> 16), 0), num = blob_int(ls.blob, ls.off_lrange + (int)(h >> 16), 1);
+        for (int j = 0; j < num; ++j) {
+            const int id = blob_int(ls.blob, ls.off_leaf + first + j, 0);
+            if (id >= cut) break;
+            (void)slab_test_and_set(id);
+        }
+    }
+    // the history is full: everything it stands for goes into the slab, and the ray stays there
+    NDT_DEV void spill()
+    {
+        const int n = hist_n;
+        const unsigned int e0 = h0, e1 = h1, e2 = h2, e3 = h3;
+        begin_slab();
+        if (n > 0) spill_leaf(e0);
+        if (n > 1) spill_leaf(e1);
+        if (n > 2) spill_leaf(e2);
+        if (n > 3) spill_leaf(e3);
     }
 };
 
@@ -1083,7 +1170,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                         if (dist_limit == 0.0 || dist < dist_limit) {               // break
                             if (BITS) cand = 0ull;
-                            else pos = end;
+                            else end = pos;         // (not pos = end: pos - 1 stays the last item the scan looked at)
                         }
                     }
                 } else if (!in_sub && (BITS ? cand == 0ull : pos == end)) {
@@ -1211,7 +1298,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                         if (dist_limit == 0.0 || dist < dist_limit) {                               // object.c:730
                             if (BITS) cand = 0ull;
-                            else pos = end;
+                            else end = pos;         // (not pos = end: pos - 1 stays the last item the scan looked at)
                         }
                     }
                 }
@@ -1222,6 +1309,12 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
         // ---- list finished: what trace() returns to its caller
         NDT_STAMP(3);
         have_list = false;
+        if (MW == 0 && !list_is_inf) {
+            // the leaf's ordinal (its record, which `node` still names) and the last item the scan looked at
+            int last, flags_;
+            blob_ref(blob, sec + pos - 1, last, flags_);
+            mask.end_leaf(blob_int(blob, sd.off_kd + 2 * node, 1), last);
+        }
         if (list_is_inf) {
             ret_inf = min_dist >= 0;
             if (min_dist > NDT_EPS) t_inf = min_dist;           // object.c:736

@@ -5,27 +5,37 @@
 #include "ndt_finish.hpp"
 #include <stddef.h>
 
-void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
+static void free_stream_args(ndt_hip_ctx *ctx)
 {
-    for (void *p : ctx->ws_allocs) (void)hipFree(p);
-    ctx->ws_allocs.clear();
-    memset(&ctx->ws, 0, sizeof(ctx->ws));
-    ctx->ws_slab_words = 0;
-    ctx->ws_dims = 0;
-    ctx->ws_nseg = 0;
+    for (void *p : ctx->sa_allocs) (void)hipFree(p);
+    ctx->sa_allocs.clear();
     memset(&ctx->sa, 0, sizeof(ctx->sa));
     ctx->sa_cap = ctx->sa_sh_cap = 0;
     ctx->sa_nseg = 0;
 }
 
+void ndt_impl::free_workspace(ndt_hip_ctx *ctx)
+{
+    for (void *p : ctx->ws_allocs) (void)hipFree(p);
+    ctx->ws_allocs.clear();
+    free_stream_args(ctx);
+    memset(&ctx->ws, 0, sizeof(ctx->ws));
+    ctx->ws_slab_words = 0;
+    ctx->ws_dims = 0;
+    ctx->ws_nseg = 0;
+}
+
 // ------------------------------------------------------------------ workspace
 
-template <typename T> static int ws_alloc(ndt_hip_ctx *ctx, T **p, size_t count)
+template <typename T> static int ws_alloc(ndt_hip_ctx *ctx, T **p, size_t count, bool stream_args = false)
 {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, (count > 0 ? count : 1) * sizeof(T));
-    if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
-    ctx->ws_allocs.push_back(q);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NDT_E_NOMEM, "hipMalloc of %zu bytes: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    (stream_args ? ctx->sa_allocs : ctx->ws_allocs).push_back(q);
     *p = (T *)q;
     return NDT_OK;
 }
@@ -47,38 +57,43 @@ int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap
     free_workspace(ctx);
     const int n = ctx->dims;
     int rc;
+    // (an allocation that fails leaves no half-built workspace behind: the next call starts from nothing)
+    auto give_up = [&](int code) {
+        free_workspace(ctx);
+        return code;
+    };
     ws.cap = cap;
     ws.sh_cap = sh_cap;
-    if ((rc = ws_alloc(ctx, &ws.ray_o, (size_t)n * cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.depth, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.rng_key, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.hit_p, (size_t)n * cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.hit_n, (size_t)n * cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.clr, (size_t)3 * cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.child_refl, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.child_refr, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sh_idx, (size_t)cap * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1)))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sh_mask, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.count, (size_t)cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.so, (size_t)n * sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sv, (size_t)n * sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.slim, (size_t)sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return rc;
-    if (ctx->shade_probe >= 0 && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return rc;
-    if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return rc;
+    if ((rc = ws_alloc(ctx, &ws.ray_o, (size_t)n * cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.ray_v, (size_t)n * cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.frac, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.depth, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.rng_key, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.depth_left, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.hit_obj, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.hit_prim, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.hit_p, (size_t)n * cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.hit_n, (size_t)n * cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.clr, (size_t)3 * cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.child_refl, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.child_refr, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.sh_idx, (size_t)cap * (ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1)))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.sh_mask, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.count, (size_t)cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.so, (size_t)n * sh_cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.sv, (size_t)n * sh_cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.slim, (size_t)sh_cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.sobj, (size_t)sh_cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.sprim, (size_t)sh_cap))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.counters, NDT_CNT_TOTAL))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.ref_rays, 64 * 8))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.dbg, 160))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return give_up(rc);
+    if (ctx->shade_probe >= 0 && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return give_up(rc);
+    if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return give_up(rc);
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
-        if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return rc;
+        if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return give_up(rc);
     }
     ctx->ws_slab_words = slab_words;
     ctx->ws_dims = ctx->dims;
@@ -88,12 +103,17 @@ int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap
 
 // The queues and counters of the streaming frame kernel for the current workspace: one fill counter, one lighting
 // counter and one ring entry per node batch, the same per shadow batch of every light's segment, a parent and a
-// wait count per node, an owner per shadow slot.  (Allocated with the workspace: free_workspace releases them.)
+// wait count per node, an owner per shadow slot.  (They belong to a workspace and a light count: free_workspace releases
+// them, and so does a change of either -- the previous set is freed, not kept until the workspace goes.)
 static int ensure_stream_args(ndt_hip_ctx *ctx)
 {
     const Workspace &ws = ctx->ws;
     const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
     if (ctx->sa.ctl && ctx->sa_cap == ws.cap && ctx->sa_sh_cap == ws.sh_cap && ctx->sa_nseg == n_seg) return NDT_OK;
+    if (!ctx->sa_allocs.empty()) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        free_stream_args(ctx);
+    }
     StreamArgs &sa = ctx->sa;
     // rings have room for a ticket per wavefront beyond the last entry (a wavefront's ticket may name a slot that is never written)
     const long long margin = NDT_STREAM_LOG_WAVES;
@@ -101,17 +121,17 @@ static int ensure_stream_args(ndt_hip_ctx *ctx)
     const long long seg_cap = (ws.sh_cap / n_seg) & ~63LL;
     const long long sh_batches = (long long)n_seg * (seg_cap / 64) + margin;
     int rc;
-    if ((rc = ws_alloc(ctx, &sa.ctl, 1))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.node_fill, (size_t)node_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.sh_pending, (size_t)node_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.sh_fill, (size_t)sh_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.sec_ring, (size_t)NDT_PRIM_SHARDS * node_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.sh_ring, (size_t)sh_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.fin_ring, (size_t)node_batches))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.parent, (size_t)ws.cap))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.pend, (size_t)ws.cap))) return rc;
-    if ((rc = ws_alloc(ctx, &sa.sowner, (size_t)n_seg * seg_cap))) return rc;
-    if (ctx->stream_probe && (rc = ws_alloc(ctx, &sa.wave_log, (size_t)24 * NDT_STREAM_LOG_WAVES))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.ctl, 1, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.node_fill, (size_t)node_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_pending, (size_t)node_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_fill, (size_t)sh_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sec_ring, (size_t)NDT_PRIM_SHARDS * node_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sh_ring, (size_t)sh_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.fin_ring, (size_t)node_batches, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.parent, (size_t)ws.cap, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.pend, (size_t)ws.cap, true))) return rc;
+    if ((rc = ws_alloc(ctx, &sa.sowner, (size_t)n_seg * seg_cap, true))) return rc;
+    if (ctx->stream_probe && (rc = ws_alloc(ctx, &sa.wave_log, (size_t)24 * NDT_STREAM_LOG_WAVES, true))) return rc;
     sa.n_seg = n_seg;
     sa.seg_cap = (int)seg_cap;
     sa.node_batches = (int)node_batches;
@@ -452,16 +472,26 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     const long long stream_upto = ctx->stream_below;
     ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= stream_upto);
     const bool hybrid = !ctx->use_stream && ctx->pipeline == 3 && ctx->hybrid_level >= 1 && rg.max_depth > ctx->hybrid_level;
+    // (auto only) the frame kernel keeps one shadow slot per node AND light for the whole frame: with many lights that can
+    // exceed what the per-bounce pipeline, which sizes its segments bounce by bounce, needs by far.  When it does not fit --
+    // 2^31 slots, or the allocation fails -- auto renders the pass per bounce instead of failing.
+    const long long cap_levels = cap, sh_cap_levels = sh_cap;
+    bool stream_gave_up = false;
     if (ctx->use_stream) {
         // ---- the streaming pipeline: one persistent launch for the whole ray tree (ndt_stream.hpp)
         const int n_seg = ctx->n_shadow_lights > 0 ? ctx->n_shadow_lights : 1;
         for (int attempt = 0; attempt < 8; ++attempt) {
             // every light's shadow segment can hold one ray per node
             if (sh_cap < cap * n_seg) sh_cap = cap * n_seg;
-            if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
-            int rc = ensure_workspace(ctx, cap, sh_cap);
+            int rc = NDT_OK;
+            if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) rc = fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");
+            if (!rc) rc = ensure_workspace(ctx, cap, sh_cap);
+            if (!rc) rc = ensure_stream_args(ctx);
+            if (rc == NDT_E_NOMEM && ctx->pipeline == 0) {
+                stream_gave_up = true;
+                break;
+            }
             if (rc) return rc;
-            if ((rc = ensure_stream_args(ctx))) return rc;
             Workspace ws = ctx->ws;
             StreamArgs sa = ctx->sa;
             sa.root_begin = 0;
@@ -535,7 +565,12 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             }
             return NDT_OK;
         }
-        return fail(NDT_E_NOMEM, "ray-tree workspace kept overflowing");
+        if (!stream_gave_up) return fail(NDT_E_NOMEM, "ray-tree workspace kept overflowing");
+        ctx->use_stream = false;
+        cap = cap_levels;
+        sh_cap = sh_cap_levels;
+        if (cap < ctx->ws.cap) cap = ctx->ws.cap;
+        if (sh_cap < ctx->ws.sh_cap) sh_cap = ctx->ws.sh_cap;
     }
     for (int attempt = 0; attempt < 8; ++attempt) {
         if (cap > 0x7fffff00LL || sh_cap > 0x7fffff00LL) return fail(NDT_E_NOMEM, "ray tree exceeds 2^31 nodes");

@@ -3,7 +3,7 @@
 // live rays of the next bounce and the shadow rays of this one are compacted with a
 // wavefront prefix sum and one atomic per wavefront.
 //
-// Kernels per bounce (host loop in ndt_host.hip):
+// Kernels per bounce (host loop: ndt_frame.hip:render_pass):
 //   k_trace        trace_kd (object.c:683) for every node of the bounce       -> (object, primitive)
 //   k_shade_emit   first half of apply_lights (ndt.c:71-259): hit point, same-side test,
 //                  spot cone, one shadow ray per light that passes            -> shadow queue
@@ -270,6 +270,29 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 
 // ------------------------------------------------------------------ trace
 
+// The visit mask of this lane's rays.  MW == 0: its words in the global slab (one column per resident lane) and, when the
+// scene carries them, the leaf sets of the history representation (ndt_device.hpp:VisitMask).
+template <int MW> NDT_DEV void init_visit_mask(VisitMask<MW> &mask, const double *gblob, const SceneDesc &sd, const Workspace &ws)
+{
+    mask.ext = nullptr;
+    mask.ext_stride = 0;
+    mask.h0 = mask.h1 = mask.h2 = mask.h3 = 0u;
+    mask.hist_n = -1;
+    mask.slab_words = sd.mask_words;
+    mask.ls.sets = nullptr;
+    mask.ls.blob = gblob;
+    mask.ls.words = sd.mask_words;
+    mask.ls.off_lrange = sd.off_lrange;
+    mask.ls.off_leaf = sd.off_leaf;
+    mask.ls.cap = sd.hist_cap;
+    if (MW == 0) {
+        const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        mask.ext = ws.mask_slab + lane_slot;
+        mask.ext_stride = (int)ws.mask_slab_lanes;
+        if (sd.off_lset > 0) mask.ls.sets = reinterpret_cast<const unsigned long long *>(gblob + sd.off_lset);
+    }
+}
+
 // One trace_kd query per lane.  LDS tier: the trace sections of the scene blob (kd nodes, leaf
 // lists, object headers, bounding spheres, parameters) are staged once per workgroup; the
 // workgroups are persistent and every wavefront pulls batches of 64 rays from a device-side
@@ -306,15 +329,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         kstack.node = (int *)(base + (size_t)depth * blockDim.x) + threadIdx.x;
     }
     VisitMask<MW> mask;
-    mask.ext = nullptr;
-    mask.ext_stride = 0;
-    mask.live0 = mask.live1 = 0ull;
-    mask.lazy = false;
-    if (MW == 0) {
-        const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        mask.ext = ws.mask_slab + lane_slot;
-        mask.ext_stride = (int)ws.mask_slab_lanes;
-    }
+    init_visit_mask<MW>(mask, gblob, sd, ws);
     const int lane = __lane_id();
     // NDT_HIP_EXIT_PROBE: when does every wavefront start, start its last batch, and run out of work
     const unsigned int probe_start = job.exit_log ? (unsigned int)wall_clock64() : 0u;

@@ -1,4 +1,4 @@
-// ndt_kernels.hpp -- launch interface between the host driver (ndt_host.hip) and the
+// ndt_kernels.hpp -- launch interface between the host side (ndt_frame.hip, ndt_api.hip) and the
 // per-dimension kernel translation units (ndt_kernels.hip compiled once per N).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -148,12 +148,19 @@ static CtxWorker *worker_of(ndt_hip_ctx *ctx)
 }
 
 // what context k does for its share of the frame: render rows (begin, step) into its own shard buffer, then push them
-// into `d_dst` (the assembled image on the first context's device) -- directly when this device can store there,
-// through a staging copy on that device otherwise
+// into `d_dst` (the assembled image on the first context's device).  Three ways, reported by ndt_hip_multi_path_taken():
+//   NDT_MULTI_LOCAL   the context lives on the first context's device: plain stores
+//   NDT_MULTI_PEER    another device with peer access: the push kernel stores over xGMI into the first device's HBM
+//   NDT_MULTI_STAGED  no peer access (or option "multi_path" 2): the shard travels as ONE runtime copy (hipMemcpyPeerAsync)
+//                     into this context's staging buffer on the first device and is pushed from there by a kernel of that
+//                     device, on a stream of that device this context owns -- buffer and stream are kept between frames
+// Option "multi_path": 0 auto (local / peer / staged in that order of preference), 1 never staged (fails without peer
+// access), 2 always staged -- also for a context on the first device, which is how the staged path is tested on one GPU.
 static int render_and_push(ndt_hip_ctx *ctx, ndt_hip_ctx *first, ndt_render_params sp, int format, void *d_dst, int row0_out,
                            int step_out, ndt_render_stats *st)
 {
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->multi_path_taken = NDT_MULTI_NONE;
     const int rows = ndt_hip_shard_rows(sp.height, sp.row_begin, sp.row_step);
     if (rows <= 0) {
         *st = ndt_render_stats{};
@@ -163,38 +170,82 @@ static int render_and_push(ndt_hip_ctx *ctx, ndt_hip_ctx *first, ndt_render_para
     int rc = ensure_bytes(ctx, &ctx->d_shard, &ctx->d_shard_bytes, shard_bytes);
     if (rc) return rc;
     if ((rc = ndt_hip_render_device(ctx, &sp, ctx->d_shard, st))) return rc;
-    bool direct = ctx->device == first->device;
-    if (!direct) {
-        // peer stores: enabled once per (device, peer) pair; "already enabled" is success
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, ctx->device, first->device) == hipSuccess && can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(first->device, 0);
-            direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
-            (void)hipGetLastError();
+    int path = NDT_MULTI_STAGED;
+    if (ctx->multi_path != 2) {
+        if (ctx->device == first->device) {
+            path = NDT_MULTI_LOCAL;
+        } else {
+            // peer stores: enabled once per (device, peer) pair; "already enabled" is success
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ctx->device, first->device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(first->device, 0);
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) path = NDT_MULTI_PEER;
+                (void)hipGetLastError();
+            }
+            if (path == NDT_MULTI_STAGED && ctx->multi_path == 1)
+                return fail(NDT_E_DEVICE, "multi_path 1: device %d has no peer access to device %d", ctx->device, first->device);
         }
     }
-    if (direct) {
+    if (path != NDT_MULTI_STAGED) {
         launch_push(ctx->stream, format, ctx->d_shard, d_dst, sp.width, rows, row0_out, step_out);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->multi_path_taken = path;
         return NDT_OK;
     }
-    // no peer access: the shard travels as one copy into a staging buffer of the first context's device (one per
-    // source context, so that the copies of different contexts do not wait for each other), and is pushed from there
+    // staged: buffer and stream live on the FIRST device and belong to this context (one per source context, so that the
+    // copies of different contexts do not wait for each other)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipSetDevice(first->device));
-    void *stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, shard_bytes));
-    hipError_t e = hipMemcpyPeer(stage, first->device, ctx->d_shard, ctx->device, shard_bytes);
-    if (e == hipSuccess) {
-        launch_push(nullptr, format, stage, d_dst, sp.width, rows, row0_out, step_out);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    hipError_t e = hipSetDevice(first->device);
+    if (e == hipSuccess && ctx->d_stage && ctx->stage_device != first->device) {
+        // the first context changed devices since the last frame: the old staging area goes
+        (void)hipSetDevice(ctx->stage_device);
+        (void)hipStreamDestroy(ctx->stage_stream);
+        (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->stage_stream = nullptr;
+        ctx->d_stage_bytes = 0;
+        e = hipSetDevice(first->device);
     }
-    (void)hipFree(stage);
+    if (e == hipSuccess && !ctx->stage_stream) {
+        e = hipStreamCreateWithFlags(&ctx->stage_stream, hipStreamNonBlocking);
+        ctx->stage_device = first->device;
+    }
+    if (e == hipSuccess && ctx->d_stage_bytes < shard_bytes) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->d_stage_bytes = 0;
+        e = hipMalloc(&ctx->d_stage, shard_bytes);
+        if (e == hipSuccess) ctx->d_stage_bytes = shard_bytes;
+    }
+    if (e == hipSuccess) e = hipMemcpyPeerAsync(ctx->d_stage, first->device, ctx->d_shard, ctx->device, shard_bytes, ctx->stage_stream);
+    if (e == hipSuccess) {
+        launch_push(ctx->stage_stream, format, ctx->d_stage, d_dst, sp.width, rows, row0_out, step_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stage_stream);
     (void)hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(NDT_E_DEVICE, "staged gather from device %d: %s", ctx->device, hipGetErrorString(e));
+    ctx->multi_path_taken = NDT_MULTI_STAGED;
     return NDT_OK;
+}
+
+extern "C" int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx) { return ctx ? ctx->multi_path_taken : NDT_MULTI_NONE; }
+
+// (ndt_hip_destroy) the staging area lives on another device than the context
+void ndt_impl::free_stage(ndt_hip_ctx *ctx)
+{
+    if (!ctx->d_stage && !ctx->stage_stream) return;
+    (void)hipSetDevice(ctx->stage_device);
+    if (ctx->stage_stream) {
+        (void)hipStreamSynchronize(ctx->stage_stream);
+        (void)hipStreamDestroy(ctx->stage_stream);
+    }
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->d_stage = nullptr;
+    ctx->stage_stream = nullptr;
+    ctx->d_stage_bytes = 0;
+    (void)hipSetDevice(ctx->device);
 }
 
 extern "C" int ndt_hip_render_multi_device(ndt_hip_ctx *const *ctxs, int32_t n_ctx, const ndt_render_params *p, int32_t format,

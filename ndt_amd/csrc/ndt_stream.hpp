@@ -665,15 +665,7 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
         kstack.node = (int *)(base + (size_t)depth * blockDim.x) + threadIdx.x;
     }
     VisitMask<MW> mask;
-    mask.ext = nullptr;
-    mask.ext_stride = 0;
-    mask.live0 = mask.live1 = 0ull;
-    mask.lazy = false;
-    if (MW == 0) {
-        const long long lane_slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        mask.ext = ws.mask_slab + lane_slot;
-        mask.ext_stride = (int)ws.mask_slab_lanes;
-    }
+    init_visit_mask<MW>(mask, gblob, sd, ws);
     // Idle wavefronts: ONE per workgroup (the first: the watcher) looks at the frame's global words -- is everything done, are
     // there partial batches to close -- and tells the others through LDS.  With every idle wavefront doing that (a dozen
     // agent-scope loads of the same few words per round) a launch with more wavefronts than work spent its time in the queue
@@ -920,6 +912,10 @@ static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd,
     // work items of a frame: a few per primary batch; a grid beyond that cannot help
     auto grid_for_work = [&](int res, int block) {
         long long want = (batches * 3 + (block / 64) - 1) / (block / 64) + 1;
+        // the rings carry a margin of NDT_STREAM_LOG_WAVES entries beyond the last batch: one per wavefront that may hold a
+        // ticket for a slot nobody writes (ensure_stream_args), so the grid never has more wavefronts than that
+        const long long by_margin = NDT_STREAM_LOG_WAVES / (block / 64);
+        if (res > by_margin) res = (int)by_margin;
         // (more workgroups than are resident would be safe -- a ticket is only ever held by a running wavefront -- but
         // they would only start when others leave: measured with 256-lane workgroups, of which the occupancy query
         // admits one per CU and so does the hardware, half of a 2x grid started when the frame was over)

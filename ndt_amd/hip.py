@@ -20,10 +20,11 @@ API_SYMBOLS = [
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
     "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
-    "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option",
+    "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
 ]
 
 IMAGE_F64, IMAGE_RGBA8 = 0, 1      # enum ndt_image_format
+MULTI_NONE, MULTI_LOCAL, MULTI_PEER, MULTI_STAGED = 0, 1, 2, 3     # enum ndt_multi_path
 
 
 class NdtHipError(RuntimeError):
@@ -73,6 +74,7 @@ def load_library():
     lib.ndt_hip_render_multi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_device.argtypes = [C.c_void_p]
+    lib.ndt_hip_multi_path_taken.argtypes = [C.c_void_p]
     lib.ndt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = lib
     return lib
@@ -145,6 +147,10 @@ class NdtHip:
     def set_option(self, name, value):
         """ndt_hip_set_option: "pipeline" (0 auto, 1 levels, 2 stream, 3 hybrid), "hull_box", "face_box", "debug_levels", ..."""
         self._check(self.lib.ndt_hip_set_option(self.ctx, name.encode(), int(value)))
+
+    def multi_path_taken(self):
+        """ndt_hip_multi_path_taken: how this context's rows reached the frame in the last render_multi (MULTI_*)."""
+        return int(self.lib.ndt_hip_multi_path_taken(self.ctx))
 
     def upload_scene(self, fs):
         self._check(self.lib.ndt_hip_upload_scene(self.ctx, fs.byref()))

@@ -100,80 +100,90 @@ void camera_zoom(camera *cam)
     vectNd_scale(&cam->dirY, 1 / cam->zoom, &cam->dirY);
 }
 
-/* camera.c:180-327: place the default camera at viewPoint, roll it by rotation+leveling in the
- * screen plane, then for every ordered pair of axes (i,j) rotate it in that plane by the angle
- * that lines imgOrig up with the target as seen in that plane */
+/* ---- camera_aim_naive (camera.c:180-327) as a rig of points that turn together.
+ *
+ * The default camera looks down one axis from the origin.  Aiming it = moving it to viewPoint and turning it, one
+ * coordinate plane at a time, until the screen centre lies in the direction of the target.  What turns is a RIG: the
+ * screen centre, one point a screen-width to its right and one a screen-height above it (the screen axes are read back
+ * from them afterwards), and the two eyes.  The order of the turns and the snapping of small offsets to zero decide the
+ * last bits of the aimed camera -- and through it every pixel -- so both are the reference's. */
+
+/* direction of `to` seen from `from`, inside the (i, j) coordinate plane; offsets below EPSILON count as none */
+static double bearing_in_plane(const vectNd *from, const vectNd *to, int i, int j)
+{
+    double along = to->v[i] - from->v[i];
+    double across = to->v[j] - from->v[j];
+    if (fabs(across) < EPSILON) across = 0;
+    if (fabs(along) < EPSILON) along = 0;
+    return atan2(across, along);
+}
+
+#define RIG_POINTS 5
+static void rig_turn(vectNd *const rig[RIG_POINTS], const vectNd *about, int i, int j, double angle)
+{
+    for (int k = 0; k < RIG_POINTS; ++k) vectNd_rotate(rig[k], about, i, j, angle, rig[k]);
+}
+
 int camera_aim_naive(camera *cam)
 {
     const int dim = cam->pos.n;
-    vectNd pos, target, px, py;
-    vectNd_calloc(&pos, dim);
+    /* what the caller configured survives the reset below */
+    const camera keep = *cam;           /* scalars only are read from this copy: its vectors alias cam's */
+    vectNd from, target, right, above;
+    vectNd_calloc(&from, dim);
     vectNd_calloc(&target, dim);
-    vectNd_copy(&pos, &cam->viewPoint);
+    vectNd_copy(&from, &cam->viewPoint);
     vectNd_copy(&target, &cam->viewTarget);
-    const double rot = cam->rotation + cam->leveling;
-    const double zoom = cam->zoom, hFov = cam->hFov, vFov = cam->vFov;
-    const double aperture = cam->aperture_radius, focal_distance = cam->focal_distance;
-    const int flip_x = cam->flip_x, flip_y = cam->flip_y, flatten = cam->flatten;
-    const camera_type_t type = cam->type;
+    const double roll = keep.rotation + keep.leveling;
 
     camera_reset(cam);
-    cam->type = type;
-    vectNd_copy(&cam->viewPoint, &pos);
+    cam->type = keep.type;
+    vectNd_copy(&cam->viewPoint, &from);
     vectNd_copy(&cam->viewTarget, &target);
-    cam->rotation = rot;                    /* sic: leveling is folded in here (camera.c:215) */
+    cam->rotation = roll;               /* sic: the leveling is folded into the rotation (camera.c:215) */
     cam->eye_offset = EYE_OFFSET;
-    cam->zoom = zoom;
-    cam->flip_x = flip_x; cam->flip_y = flip_y; cam->flatten = flatten;
-    cam->hFov = hFov; cam->vFov = vFov;
-    cam->aperture_radius = aperture;
-    cam->focal_distance = focal_distance;
+    cam->zoom = keep.zoom;
+    cam->flip_x = keep.flip_x; cam->flip_y = keep.flip_y; cam->flatten = keep.flatten;
+    cam->hFov = keep.hFov; cam->vFov = keep.vFov;
+    cam->aperture_radius = keep.aperture_radius;
+    cam->focal_distance = keep.focal_distance;
 
-    double target_dist = 0.0, focal_len = 0.0;
-    vectNd_dist(&pos, &target, &target_dist);
-    vectNd_l2norm(&cam->imgOrig, &focal_len);
+    /* the screen goes out to the target's distance, keeping its opening angle */
+    double reach = 0.0, default_reach = 0.0;
+    vectNd_dist(&from, &target, &reach);
+    vectNd_l2norm(&cam->imgOrig, &default_reach);
     vectNd_unitize(&cam->imgOrig);
-    vectNd_scale(&cam->imgOrig, target_dist, &cam->imgOrig);
-    vectNd_scale(&cam->dirX, target_dist / focal_len, &cam->dirX);
-    vectNd_scale(&cam->dirY, target_dist / focal_len, &cam->dirY);
+    vectNd_scale(&cam->imgOrig, reach, &cam->imgOrig);
+    vectNd_scale(&cam->dirX, reach / default_reach, &cam->dirX);
+    vectNd_scale(&cam->dirY, reach / default_reach, &cam->dirY);
 
-    /* two screen points that follow the rotations */
-    vectNd_alloc(&px, dim);
-    vectNd_add(&cam->imgOrig, &cam->dirX, &px);
-    vectNd_alloc(&py, dim);
-    vectNd_add(&cam->imgOrig, &cam->dirY, &py);
+    /* the rig, moved to the view point */
+    vectNd_alloc(&right, dim);
+    vectNd_add(&cam->imgOrig, &cam->dirX, &right);
+    vectNd_alloc(&above, dim);
+    vectNd_add(&cam->imgOrig, &cam->dirY, &above);
+    vectNd_add(&cam->pos, &from, &cam->pos);
+    vectNd_add(&cam->leftEye, &from, &cam->leftEye);
+    vectNd_add(&cam->rightEye, &from, &cam->rightEye);
+    vectNd_add(&right, &from, &right);
+    vectNd_add(&above, &from, &above);
+    vectNd_add(&cam->imgOrig, &from, &cam->imgOrig);
+    vectNd *const rig[RIG_POINTS] = { &right, &above, &cam->imgOrig, &cam->leftEye, &cam->rightEye };
 
-    vectNd_add(&cam->pos, &pos, &cam->pos);
-    vectNd_add(&cam->leftEye, &pos, &cam->leftEye);
-    vectNd_add(&cam->rightEye, &pos, &cam->rightEye);
-    vectNd_add(&px, &pos, &px);
-    vectNd_add(&py, &pos, &py);
-    vectNd_add(&cam->imgOrig, &pos, &cam->imgOrig);
-
-    vectNd *moving[] = { &px, &py, &cam->imgOrig, &cam->leftEye, &cam->rightEye };
-    for (int k = 0; k < 5; ++k) vectNd_rotate(moving[k], &cam->pos, 0, 1, rot, moving[k]);
-
-    for (int i = 0; i < dim; ++i) {
+    /* the roll first, in the screen's own plane; then every ordered pair of axes */
+    rig_turn(rig, &cam->pos, 0, 1, roll);
+    for (int i = 0; i < dim; ++i)
         for (int j = 0; j < dim; ++j) {
             if (i == j) continue;
-            double cam_rise = cam->imgOrig.v[j] - cam->pos.v[j];
-            double cam_run = cam->imgOrig.v[i] - cam->pos.v[i];
-            double tar_rise = target.v[j] - cam->pos.v[j];
-            double tar_run = target.v[i] - cam->pos.v[i];
-            if (fabs(cam_rise) < EPSILON) cam_rise = 0;
-            if (fabs(cam_run) < EPSILON) cam_run = 0;
-            if (fabs(tar_rise) < EPSILON) tar_rise = 0;
-            if (fabs(tar_run) < EPSILON) tar_run = 0;
-            double cam_angle = atan2(cam_rise, cam_run);
-            double tar_angle = atan2(tar_rise, tar_run);
-            if (tar_angle < cam_angle) tar_angle += 2 * M_PI;
-            double angle = tar_angle - cam_angle;
-            for (int k = 0; k < 5; ++k) vectNd_rotate(moving[k], &cam->pos, i, j, angle, moving[k]);
+            const double have = bearing_in_plane(&cam->pos, &cam->imgOrig, i, j);
+            double want = bearing_in_plane(&cam->pos, &target, i, j);
+            if (want < have) want += 2 * M_PI;
+            rig_turn(rig, &cam->pos, i, j, want - have);
         }
-    }
 
-    vectNd_sub(&px, &cam->imgOrig, &cam->dirX);
-    vectNd_sub(&py, &cam->imgOrig, &cam->dirY);
+    /* the screen axes and the camera's local frame, read back from the rig */
+    vectNd_sub(&right, &cam->imgOrig, &cam->dirX);
+    vectNd_sub(&above, &cam->imgOrig, &cam->dirY);
     vectNd_copy(&cam->localX, &cam->dirX);
     vectNd_copy(&cam->localY, &cam->dirY);
     vectNd_sub(&cam->imgOrig, &cam->pos, &cam->localZ);
@@ -181,10 +191,10 @@ int camera_aim_naive(camera *cam)
     vectNd_unitize(&cam->localY);
     vectNd_unitize(&cam->localZ);
     cam->prepared = 1;
-    vectNd_free(&px); vectNd_free(&py); vectNd_free(&pos); vectNd_free(&target);
-    if (flip_x) camera_flip_x(cam);
-    if (flip_y) camera_flip_y(cam);
-    if (zoom != 1.0) camera_zoom(cam);
+    vectNd_free(&right); vectNd_free(&above); vectNd_free(&from); vectNd_free(&target);
+    if (keep.flip_x) camera_flip_x(cam);
+    if (keep.flip_y) camera_flip_y(cam);
+    if (keep.zoom != 1.0) camera_zoom(cam);
     return 1;
 }
 

@@ -9,11 +9,13 @@ static __thread ndt_hip_ctx *g_ctx[NDT_MAX_CTX];
 static __thread int g_n_ctx = 0;            /* contexts that exist */
 static __thread int g_want_ctx = 1;         /* contexts a frame is spread over */
 static __thread int g_first_device = 0;
+static __thread int g_paths_said = 0;
 
 static void drop_contexts(void)
 {
     for (int k = 0; k < g_n_ctx; ++k) ndt_hip_destroy(g_ctx[k]);
     g_n_ctx = 0;
+    g_paths_said = 0;
 }
 
 void ndt_render_use_device(int device)
@@ -85,6 +87,16 @@ static int render_any(scene *scn, int width, int height, int samples, int aa_dif
             ok = format == NDT_IMAGE_F64 && ndt_hip_render_depth(g_ctx[0], &p, (double *)out, depth, NULL) == NDT_OK;
         else
             ok = ndt_hip_render_multi(g_ctx, g_n_ctx, &p, format, out, NULL) == NDT_OK;
+        if (ok && g_n_ctx > 1 && !g_paths_said) {
+            /* once per thread: how every context's rows reached the frame (an N-GPU run is diagnosable from its log) */
+            static const char *const names[] = { "no rows", "same device", "peer stores", "staged copy" };
+            g_paths_said = 1;
+            fprintf(stderr, "ndt_render_image: one frame over %d contexts:", g_n_ctx);
+            for (int k = 0; k < g_n_ctx; ++k) {
+                const int path = ndt_hip_multi_path_taken(g_ctx[k]);
+                fprintf(stderr, " [%d] GPU %d %s%s", k, ndt_hip_device(g_ctx[k]), names[path >= 0 && path <= 3 ? path : 0], k + 1 < g_n_ctx ? "," : "\n");
+            }
+        }
     }
     if (!ok) fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
     ndt_flat_builder_free(&fb);

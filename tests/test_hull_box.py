@@ -1,4 +1,4 @@
-"""The hcube hull box (ndt_host.hip:hcube_hull_box, ndt_hip_hcube_hull_box) is the one place
+"""The hcube hull box (ndt_blob.hip:hcube_hull_box, ndt_hip_hcube_hull_box) is the one place
 where the device does LESS than the reference: a ray that misses the box skips the nested
 trace() over the hcube's faces (hcube.c:241).  That is only legitimate if no point the
 reference can return for a face lies outside the box.  Checked here
