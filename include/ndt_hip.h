@@ -289,6 +289,9 @@ int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
  *                                primaries and writing its pixels itself (tests prove it neutral)
  *   "item_sets"               0: upload a scene of up to 64 items with plain leaf lists (the kernels that read the lists,
  *                                as for larger scenes) instead of 64-bit item sets per leaf (tests prove it neutral)
+ *   "item_boxes"              0: upload scenes of more than 256 items without the item boxes (ndt_hip_item_boxes)
+ *   "leaf_scan" / "leaf_scan_group"   global-memory tier: the lanes of a wavefront that stand on the same kd leaf scan it
+ *                                together through LDS (0: never) when at least that many of them do (default 64: all)
  *   "leaf_history"            scenes in the global-memory tier (more than 256 items): a ray remembers what it visited as up to
  *                                this many {leaf, cut} pairs (default and maximum 4) before it falls back to its bit mask in
  *                                the slab; 0: the slab only (tests prove every value neutral)
@@ -323,6 +326,13 @@ int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *
  * bit f of *possible is clear when face f can never be hit.  Returns the number of faces, 0 when the
  * hcube has no face boxes (no hull box, or more than 63 faces), <0 on NDT_E_*. */
 int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double *face_rows, uint64_t *possible);
+
+/* Diagnostic, host only: the item boxes the library derives at upload for scenes of more than 256 items -- one orthonormal
+ * frame for the scene (frame: dims x unit axis[dims]) and, for every top-level orthotope, the box in that frame of every
+ * point its intersect() can return (rows: n_items x dims x { centre coordinate, half extent }; has[i] != 0: item i carries
+ * one).  A ray that misses an item's box skips its bounding-sphere gate and its intersect(); tests prove that neutral.
+ * Returns the number of boxed items (0: none), <0 on NDT_E_*. */
+int ndt_hip_item_boxes(const ndt_flat_scene *scene, double *frame, double *rows, uint8_t *has);
 
 /* The stream the context launches on (a hipStream_t), for callers that time with their own
  * events or order other work against it. */

@@ -406,6 +406,115 @@ bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o
     return true;
 }
 
+// Item boxes: the face boxes of an hcube, for the orthotopes that stand in the scene on their own (the 6-D .. 8-D
+// hypercubes of scenes/hypercube.c are thousands of them: every m-face of the cube is an orthotope of its own, behind a
+// bounding sphere as wide as its diagonal -- 44 % of the sphere gates pass, and a ray that crosses the cube intersects a
+// hundred faces to hit one).  ONE orthonormal frame for the whole scene (Gram-Schmidt of the orthotopes' own axes: for a
+// cube, rotated or not, its edges), and per orthotope the box, in that frame, of everything its intersect() can return --
+// hcube_hull_box's derivation, one object at a time, same margin.  A ray projects itself on the frame once (2N dot
+// products, the first time it meets a boxed item) and then tests an item with N slab updates; an item whose box it misses
+// cannot be hit in the reference's arithmetic, so neither its gate nor its intersect() is run -- the answer they would
+// give is "no hit" (ndt_device.hpp:item_box_meets).
+//   frame: N x unit axis[N];  rows: n_items x N x { centre, half extent };  has[i] = item i carries a box
+bool ndt_impl::scene_item_boxes(const ndt_flat_scene *fs, int n, std::vector<double> &frame, std::vector<double> &rows,
+                                std::vector<char> &has)
+{
+    has.assign((size_t)(fs->n_items > 0 ? fs->n_items : 1), 0);
+    rows.assign((size_t)(fs->n_items > 0 ? fs->n_items : 0) * 2 * n, 0.0);
+    frame.clear();
+    std::vector<std::vector<double>> pts_of((size_t)(fs->n_items > 0 ? fs->n_items : 0));
+    std::vector<std::vector<double>> axes;
+    int boxed = 0;
+    for (int i = 0; i < fs->n_items; ++i) {
+        const ndt_flat_object &f = fs->objects[i];
+        if (f.type != NDT_OBJ_ORTHOTOPE || f.n_flag < 1 || f.n_pos < 1) continue;
+        if (f.flag_off < 0 || (int64_t)f.flag_off + f.n_flag > fs->n_flags) continue;
+        const int m = fs->flags[f.flag_off];
+        if (m < 1 || m > f.n_dir || m > n || m > 16) continue;
+        if (!vec_ok(fs, f.pos_off, 1) || !vec_ok(fs, f.dir_off, m)) continue;
+        std::vector<double> pts;
+        if (!face_region_corners(fs->vecs + f.pos_off, fs->vecs + f.dir_off, m, n, pts) || pts.empty()) continue;
+        bool finite = true;
+        for (double x : pts)
+            if (!std::isfinite(x)) finite = false;
+        if (!finite) continue;
+        pts_of[(size_t)i].swap(pts);
+        ++boxed;
+        if ((int)axes.size() < 4 * n)
+            for (int a = 0; a < m; ++a) {
+                std::vector<double> u(fs->vecs + f.dir_off + a * n, fs->vecs + f.dir_off + (a + 1) * n);
+                h_unitize(u.data(), n);
+                axes.push_back(u);
+            }
+    }
+    if (boxed == 0) return false;
+    // the frame: the orthotopes' axes as far as they are independent, then the world's
+    std::vector<std::vector<double>> fr;
+    auto complete = [&](const std::vector<std::vector<double>> &cands, double keep) {
+        for (const auto &a : cands) {
+            if ((int)fr.size() >= n) break;
+            std::vector<double> r(a);
+            for (const auto &u : fr) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += a[c] * u[c];
+                for (int c = 0; c < n; ++c) r[c] -= d * u[c];
+            }
+            const double l = h_len(r.data(), n);
+            if (l > keep) {
+                for (int c = 0; c < n; ++c) r[c] /= l;
+                fr.push_back(r);
+            }
+        }
+    };
+    std::vector<std::vector<double>> world;
+    for (int j = 0; j < n; ++j) {
+        std::vector<double> e((size_t)n, 0.0);
+        e[j] = 1.0;
+        world.push_back(e);
+    }
+    complete(axes, 0.5);
+    for (double keep = 0.5; (int)fr.size() < n && keep > 1e-4; keep *= 0.5) complete(world, keep);
+    if ((int)fr.size() < n) return false;
+    for (const auto &u : fr) frame.insert(frame.end(), u.begin(), u.end());
+    for (int i = 0; i < fs->n_items; ++i) {
+        const std::vector<double> &pts = pts_of[(size_t)i];
+        if (pts.empty()) continue;
+        const size_t np = pts.size() / n;
+        for (int a = 0; a < n; ++a) {
+            double lo = 1e300, hi = -1e300;
+            for (size_t q = 0; q < np; ++q) {
+                double d = 0;
+                for (int c = 0; c < n; ++c) d += pts[q * n + c] * fr[(size_t)a][c];
+                if (d < lo) lo = d;
+                if (d > hi) hi = d;
+            }
+            rows[((size_t)i * n + a) * 2] = 0.5 * (lo + hi);
+            rows[((size_t)i * n + a) * 2 + 1] = 0.5 * (hi - lo) + NDT_HULL_MARGIN;
+        }
+        has[(size_t)i] = 1;
+    }
+    return true;
+}
+
+extern "C" int ndt_hip_item_boxes(const ndt_flat_scene *fs, double *frame_out, double *rows_out, uint8_t *has_out)
+{
+    if (!fs || !frame_out || !rows_out || !has_out) return fail(NDT_E_INVALID, "null argument");
+    if (fs->abi_version != NDT_HIP_ABI_VERSION) return fail(NDT_E_INVALID, "flat scene ABI %d, library %d", fs->abi_version, NDT_HIP_ABI_VERSION);
+    if (fs->dims < 3 || fs->dims > NDT_MAX_DIMS) return fail(NDT_E_UNSUPPORTED, "dims %d", fs->dims);
+    if (fs->n_items < 0 || fs->n_items > fs->n_objects) return fail(NDT_E_INVALID, "n_items %d", fs->n_items);
+    std::vector<double> frame, rows;
+    std::vector<char> has;
+    if (!scene_item_boxes(fs, fs->dims, frame, rows, has)) return 0;
+    memcpy(frame_out, frame.data(), frame.size() * sizeof(double));
+    memcpy(rows_out, rows.data(), rows.size() * sizeof(double));
+    int n = 0;
+    for (int i = 0; i < fs->n_items; ++i) {
+        has_out[i] = (uint8_t)has[(size_t)i];
+        n += has[(size_t)i] != 0;
+    }
+    return n;
+}
+
 int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
 {
     const int n = fs->dims;
@@ -524,7 +633,13 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     }
     sd.off_child = b.push_ref_list(child_list, ref_patch);
 
+    // ---- item boxes (scene_item_boxes): for scenes that will live in global memory -- more than 256 items
+    std::vector<double> ib_frame, ib_rows;
+    std::vector<char> ib_has;
+    const bool item_boxes = ctx->item_boxes && sd.mask_words > NDT_MASK_REG_WORDS && scene_item_boxes(fs, n, ib_frame, ib_rows, ib_has);
+
     // ---- per-type parameters = the plugins' prepare() output
+    int max_param_words = 0;
     sd.off_params = b.words();
     for (int i = 0; i < fs->n_objects; ++i) {
         const ndt_flat_object &o = fs->objects[i];
@@ -539,6 +654,7 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         int flags = o.type;
         if (o.bounds_radius > 0) flags |= NDT_F_GATE;
         if (o.transparent) flags |= NDT_F_TRANSPARENT;
+        if (item_boxes && i < fs->n_items && ib_has[(size_t)i]) flags |= NDT_F_OBOX;
         int aux0 = 0, aux1 = 0;
         const int p = b.words() - sd.off_params;
         double tmp[NDT_MAX_DIMS], ax[NDT_MAX_DIMS];
@@ -684,6 +800,11 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             break;
         }
         }
+        // (every type but hcube: aux0 = the words of its parameter record, for the coherent leaf scan's staging copy)
+        if (o.type != NDT_OBJ_HCUBE) {
+            aux0 = b.words() - sd.off_params - p;
+            if (aux0 > max_param_words) max_param_words = aux0;
+        }
         b.set_ints(sd.off_hdr + 2 * i, flags, p);
         b.set_ints(sd.off_hdr + 2 * i + 1, aux0, aux1);
     }
@@ -784,7 +905,21 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             }
             sd.off_lrange = b.words();
             for (size_t l = 0; l < leaf_first.size(); ++l) b.push_ints(leaf_first[l], leaf_num[l]);
+            // Coherent leaf scan (ndt_device.hpp:cls_scan): the wavefronts whose lanes stand on the same leaf stage its
+            // items through LDS.  Needs the history (a scan that stores nothing) and leaves without composites.
+            bool plain = ctx->leaf_scan;
+            for (int id : leaf_list)
+                if (fs->objects[id].type == NDT_OBJ_HCUBE) plain = false;
+            if (plain && max_param_words <= NDT_CLS_MAX_PAR_WORDS) sd.cls_par_words = (max_param_words + 1) & ~1;
+            sd.cls_min_group = ctx->leaf_scan_group;
         }
+    }
+    sd.off_oframe = sd.off_obox = 0;
+    if (item_boxes && ctx->tier == 1) {
+        sd.off_oframe = b.words();
+        for (double x : ib_frame) b.push(x);
+        sd.off_obox = b.words();
+        for (double x : ib_rows) b.push(x);
     }
     sd.total_words = b.words();
 

@@ -84,6 +84,9 @@ struct ndt_hip_ctx {
     bool hull_box = true, face_box = true, shade_pair = true;
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
+    bool item_boxes = true;         // global-memory tier: orthotopes carry a box in one scene-wide frame (ndt_blob.hip:scene_item_boxes)
+    int leaf_scan_group = 64;       // ... when at least this many lanes share the leaf
+    bool leaf_scan = true;          // global-memory tier: lanes on the same leaf stage its items through LDS (ndt_device.hpp:cls_scan)
     int leaf_history = 4;           // global-memory tier: visited = {leaf, cut} pairs per ray (VisitMask<0>); 0: the slab only; 1 .. 3: fewer pairs (tests)
     int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;
@@ -125,6 +128,7 @@ struct HullFaces {
     int n_faces = 0;
 };
 bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);
+bool scene_item_boxes(const ndt_flat_scene *fs, int n, std::vector<double> &frame, std::vector<double> &rows, std::vector<char> &has);
 int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs);
 
 // ndt_frame.hip

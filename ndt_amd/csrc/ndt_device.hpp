@@ -28,6 +28,7 @@
 #define NDT_F_TRANSPARENT 0x800
 #define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_blob.hip:hcube_hull_box) */
 #define NDT_F_FACEBOX     0x2000    /* ... followed by the mask of possible faces and every face's own box in that frame */
+#define NDT_F_OBOX        0x4000    /* the item carries a box in the scene's frame (ndt_blob.hip:scene_item_boxes) */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
 // light_type numbering of the reference, scene.h:23-31
@@ -61,6 +62,10 @@ struct SceneDesc {
     // (high half of word 0); per leaf, mask_words words = its items as a bit set, and one word {first, num} = its list
     int off_lset, off_lrange;      // off_lset == 0: no history, visit masks live in the slab
     int hist_cap;                  // history entries per ray (4; tests: 1 .. 3 force the replay into the slab)
+    int cls_par_words;             // > 0: the coherent leaf scan is on; the longest parameter record of a leaf item (even)
+    int cls_min_group;             // lanes of a wavefront that must stand on the same leaf to scan it together
+    // item boxes (global-memory tier): one orthonormal frame, N x axis[N], and per item N x { centre, half extent }
+    int off_oframe, off_obox;      // off_obox == 0: none
 };
 
 // ------------------------------------------------------------------ random streams
@@ -295,28 +300,36 @@ template <int N>
 NDT_DEV void axes_quadratic(const double *blob, int p0, int rec, int m, const double (&o)[N], const double (&v)[N],
                             double &qa, double &qb, double &qc)
 {
-    // hcylinder.c:159-185 / orthotope.c:175-199.  The reference walks the axes twice (P, then Q); here one walk feeds both
-    // sums -- every sum still adds the same terms in the same order -- so an axis record is read once.
-    double sA[N], sum_P[N], sum_Q[N], P[N], Q[N], pos[N];
-    v_zero<N>(sum_P);
-    v_zero<N>(sum_Q);
+    // hcylinder.c:159-185 / orthotope.c:175-199
+    // (one walk over the axes feeding both sums reads every axis record once instead of twice, but keeps two N-vector sums
+    // alive: measured in round 3, it cost the 8-D trace kernel 16 registers it does not have; the records now come from LDS
+    // in the coherent leaf scan, where a second read is cheap)
+    double sA[N], sum_A[N], P[N], Q[N], pos[N];
+    v_zero<N>(sum_A);
+    for (int i = 0; i < m; ++i) {
+        int a = rec + i * (N + 3);
+        double ax[N];
+        blob_vec<N>(blob, a, ax);
+        double AdA = blob[a + N + 1];
+        double VdA = v_dot<N>(v, ax);
+        v_scale<N>(ax, VdA / AdA, sA);
+        v_add<N>(sum_A, sA, sum_A);
+    }
+    v_sub<N>(sum_A, v, P);
+    v_zero<N>(sum_A);
     for (int i = 0; i < m; ++i) {
         int a = rec + i * (N + 3);
         double ax[N];
         blob_vec<N>(blob, a, ax);
         double AdA = blob[a + N + 1];
         double BdA = blob[a + N + 2];
-        double VdA = v_dot<N>(v, ax);
-        v_scale<N>(ax, VdA / AdA, sA);
-        v_add<N>(sum_P, sA, sum_P);
         double OdA = v_dot<N>(o, ax);
         v_scale<N>(ax, (OdA - BdA) / AdA, sA);
-        v_add<N>(sum_Q, sA, sum_Q);
+        v_add<N>(sum_A, sA, sum_A);
     }
-    v_sub<N>(sum_P, v, P);
     blob_vec<N>(blob, p0, pos);
     v_sub<N>(pos, o, Q);
-    v_add<N>(Q, sum_Q, Q);
+    v_add<N>(Q, sum_A, Q);
     qa = v_dot<N>(P, P);
     qb = v_dot<N>(P, Q);
     qb *= 2;
@@ -725,6 +738,49 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
     return (long long)(live & (unsigned long long)__double_as_longlong(blob[fr]));
 }
 
+// ------------------------------------------------------------------ item boxes
+//
+// The ray in the scene's box frame (ndt_blob.hip:scene_item_boxes): u_k.o and 1/(u_k.v) for the N axes, computed once per
+// ray -- the first time it meets a boxed item -- and kept in the lane's slot of the wavefront's LDS area, pair k at
+// [k * 128 + 2 * lane]: sixteen bytes a lane, one ds_read_b128 per slab.  (In registers they would be 2N more of them; the
+// 8-D trace kernel has none to spare.)
+template <int N> NDT_DEV void ray_in_box_frame(const double *blob, const SceneDesc &sd, const double (&o)[N], const double (&v)[N], double *slot)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double u[N];
+        blob_vec<N>(blob, sd.off_oframe + k * N, u);
+        const double d = v_dot<N>(u, v);
+        ndt_v2d pr;
+        pr.x = v_dot<N>(u, o);
+        pr.y = (fabs(d) < 1e-200) ? 0.0 : 1.0 / d;          // 0 marks a ray parallel to slab k
+        *reinterpret_cast<ndt_v2d *>(slot + k * 128) = pr;
+    }
+}
+// Ray (t >= 0) against the box of item `id`: false = the ray misses it, so intersect() cannot accept a point of this item
+// (same slab arithmetic as hull_faces, same margin argument); true decides nothing.
+template <int N> NDT_DEV bool item_box_meets(const double *blob, const SceneDesc &sd, int id, const double *slot)
+{
+    const int q = sd.off_obox + id * 2 * N;
+    double t0 = 0.0, t1 = NDT_DBL_MAX;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const ndt_v2d pr = *reinterpret_cast<const ndt_v2d *>(slot + k * 128);
+        const ndt_v2d box = blob_pair(blob, q + 2 * k);
+        const double a = pr.x - box.x, h = box.y;
+        if (pr.y == 0.0) {
+            if (fabs(a) > h) ok = false;
+        } else {
+            const double ta = (-h - a) * pr.y, tb = (h - a) * pr.y;
+            const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            if (lo > t0) t0 = lo;
+            if (hi < t1) t1 = hi;
+        }
+    }
+    return ok && t0 <= t1;
+}
+
 // ------------------------------------------------------------------ trace / kd-tree
 
 // Per-ray visit mask (the reference callocs obj_num bytes per ray, kd-tree.c:600).
@@ -833,6 +889,26 @@ template <int MW> struct VisitMask {
             return seen;
         }
     }
+    // history only: bit j set = item ids[j] was visited.  Eight items at once: per history entry the eight set words are
+    // fetched before any is looked at (one round trip, not eight).
+    NDT_DEV unsigned int seen_of_8(const int (&ids)[8]) const
+    {
+        unsigned int seen = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e < hist_n) {
+                const unsigned int h = (e == 0) ? h0 : (e == 1) ? h1 : (e == 2) ? h2 : h3;
+                const unsigned long long *row = ls.sets + (size_t)(h >> 16) * ls.words;
+                unsigned long long wd[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wd[j] = row[ids[j] >> 6];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (((wd[j] >> (ids[j] & 63)) & 1ull) != 0ull && (unsigned int)ids[j] < (h & 0xffffu)) seen |= 1u << j;
+            }
+        }
+        return seen;
+    }
     // the scan of kd leaf `leaf` is over; `last` = the last item it looked at (-1: none)
     NDT_DEV void end_leaf(int leaf, int last)
     {
@@ -872,6 +948,201 @@ template <int MW> struct VisitMask {
     }
 };
 
+
+// ------------------------------------------------------------------ coherent leaf scan (global-memory tier)
+//
+// In the 6-D .. 8-D scenes a leaf holds 60 .. 227 items and the 64 rays of a wavefront -- an 8x8 pixel tile, or 64 shadow
+// rays towards one light -- nearly always scan the same leaf.  Item by item, trace()'s loop is a chain of dependent reads:
+// list entry -> bounding sphere -> (gate passes) header -> parameter record; under load each is ~0.8 us, a launch lasts as
+// long as its slowest batch (686 such steps), and the wavefronts spent half their life in s_waitcnt.  Here the lanes that
+// stand on the same leaf scan it TOGETHER, 64 list entries at a time, with the WHOLE wavefront fetching:
+//   window    lane i fetches entry i, its header words and its bounding sphere into the wavefront's window in LDS: two
+//             round trips for 64 items instead of two per item;
+//   gates     every scanning lane walks the window and gates each item against ITS ray with its CURRENT min_dist: a
+//             superset of the items it will intersect (min_dist only shrinks; the gate only gets stricter).  No memory;
+//   items     the items some lane wants are intersected in list order.  Their parameter records come through two LDS
+//             buffers: the record of the next wanted item is on its way while this one is intersected.  Right before an item
+//             a lane repeats the gate with the min_dist it has by then -- the reference's gate at the reference's moment.
+// Per ray nothing changes: the same items in the same order, the same gate with the same min_dist, the same accept and
+// break rules (object.c:692-747, bounding.c:34-85); what changes is who fetches what, and when.  Visited items are known
+// from the leaf history (VisitMask<0>), so the scan stores nothing.  Leaves that hold composites (hcube) take the old path.
+struct ClsLds {
+    double *base;       // this wavefront's window; nullptr = off
+    int min_group;      // lanes that must share a leaf for the scan to be done together
+};
+// 64 entries, 64 x {param_off, words | m << 16}, 64 x 2N words (an item's box rows, or its bounding sphere when it has no
+// box), two records (2 header words + the sphere + par_words of parameters each)
+template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words); }
+#define NDT_CLS_MAX_PAR_WORDS (128 - 12)     /* sphere + parameters are fetched as two words per lane (N <= 10) */
+
+NDT_DEV void cls_lds_sync()
+{
+    // LDS traffic between lanes of ONE wavefront: the hardware keeps a wavefront's LDS operations in order; this only
+    // keeps the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Called by ALL lanes of the wavefront (the fetching is everybody's); `mine` = this lane's ray stands on list [w0, e0) of
+// the global blob and knows what it has visited from its history.  For those lanes: the list's result like trace() --
+// min_dist (-1: nothing accepted), the accepted item -- and the last item the scan looked at.
+// box_slot / boxed: the ray's projections on the item boxes' frame (ray_in_box_frame), made here when the ray has none yet.
+template <int N, int MW>
+NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<MW> &mask, double *win, const bool mine,
+                      const double (&o)[N], const double (&v)[N], const double dist_limit, const int w0, const int e0,
+                      double *box_slot, bool &boxed, double &min_dist, int &best, int &last)
+{
+    const int lane = __lane_id();
+    double *l_ref = win, *l_inf = win + 64, *l_win = win + 128, *l_par = win + 128 + 64 * 2 * N;
+    const int par_stride = 2 + N + 2 + sd.cls_par_words;
+    SceneDesc sd_win = sd;      // item_box_meets / bsphere_gate on the window: item k's 2N words at k * 2N
+    sd_win.off_obox = 0;
+    SceneDesc sd_par = sd;      // a staged record: header at words 0 .. 1, the sphere at 2, parameters behind it
+    sd_par.off_hdr = 0;
+    sd_par.off_bs = 2;
+    sd_par.off_params = 2 + N + 2;
+    bool open = mine;           // still scanning (object.c:730 ends a scan early)
+    min_dist = -1;
+    best = -1;
+    last = -1;
+    if (mine && box_slot && !boxed) {
+        ray_in_box_frame<N>(blob, sd, o, v, box_slot);
+        boxed = true;
+    }
+    for (int base = w0; base < e0; base += 64) {
+        if (__ballot(open) == 0ull) break;
+        const int cnt = (e0 - base < 64) ? e0 - base : 64;
+        // ---- the window: entry, header and box (or sphere) of the next `cnt` items, one per lane
+        if (lane < cnt) {
+            const double ref = blob[base + lane];
+            const long long rbits = __double_as_longlong(ref);
+            const int id = (int)(rbits & 0xffffffffll);
+            const bool has_box = ((int)(rbits >> 32) & NDT_F_OBOX) != 0;
+            const ndt_v2d hdr = blob_pair(blob, sd.off_hdr + 2 * id);
+            // (2N words from either place: behind a sphere's N + 2 words the next sphere follows, and the blob goes on behind the last)
+            const int src = has_box ? sd.off_obox + id * 2 * N : sd.off_bs + id * (N + 2);
+            ndt_v2d w2[N];
+            if (has_box) {
+#pragma unroll
+                for (int c = 0; c < N; ++c) w2[c] = blob_pair(blob, src + 2 * c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    w2[c].x = blob[src + 2 * c];
+                    w2[c].y = blob[src + 2 * c + 1];
+                }
+            }
+            l_ref[lane] = ref;
+            const long long h0 = __double_as_longlong(hdr.x), h1 = __double_as_longlong(hdr.y);
+            l_inf[lane] = __longlong_as_double(((h0 >> 32) & 0xffffffffll) | (((h1 & 0xffffll) | ((h1 >> 32) << 16)) << 32));
+#pragma unroll
+            for (int c = 0; c < N; ++c) *reinterpret_cast<ndt_v2d *>(l_win + lane * 2 * N + 2 * c) = w2[c];
+        }
+        cls_lds_sync();
+        // ---- which of them this ray has visited already (rays past their first leaf)
+        unsigned long long seen = 0ull;
+        if (open && mask.hist_n > 0) {
+            for (int k0 = 0; k0 < cnt; k0 += 8) {
+                int ids[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ids[j] = (int)(__double_as_longlong(l_ref[(k0 + j < cnt) ? k0 + j : cnt - 1]) & 0xffffffffll);
+                seen |= (unsigned long long)mask.seen_of_8(ids) << k0;
+            }
+        }
+        // ---- the items this ray may have to intersect: its box, or else its sphere gate with the min_dist the ray has
+        // now (object.c:618-624; a superset, the gate is repeated at its moment below); and those any ray may
+        unsigned long long want = 0ull, any = 0ull;
+        if (__ballot(open) != 0ull) {
+            for (int k = 0; k < cnt; ++k) {
+                const int flags = __builtin_amdgcn_readfirstlane((int)(__double_as_longlong(l_ref[k]) >> 32));
+                bool pass = open;
+                if (flags & NDT_F_OBOX) {
+                    if (open) pass = item_box_meets<N>(l_win, sd_win, k, box_slot);
+                } else if (flags & NDT_F_GATE) {
+                    // (the sphere sits where a box would: N + 2 of the slot's 2N words)
+                    SceneDesc sd_sph = sd;
+                    sd_sph.off_bs = k * (2 * N) - k * (N + 2);
+                    if (open) pass = bsphere_gate<N>(l_win, sd_sph, k, o, v, min_dist);
+                }
+                if (pass) want |= 1ull << k;
+                if (__ballot(pass && !((seen >> k) & 1ull)) != 0ull) any |= 1ull << k;
+            }
+            want &= ~seen;
+        }
+        // ---- items, in list order; the record of the next one travels while this one is intersected
+        int cur = 0;
+        auto record_of = [&](int k, int &flags, int &words, int &m, int &at, int &sph) {
+            const long long ibits = __double_as_longlong(l_inf[k]);
+            const int wm = __builtin_amdgcn_readfirstlane((int)(ibits >> 32));
+            at = sd.off_params + __builtin_amdgcn_readfirstlane((int)(ibits & 0xffffffffll));
+            words = (wm & 0xffff) + N + 2;          // the sphere in front
+            m = wm >> 16;
+            const long long rbits = __double_as_longlong(l_ref[k]);
+            flags = __builtin_amdgcn_readfirstlane((int)(rbits >> 32));
+            sph = sd.off_bs + __builtin_amdgcn_readfirstlane((int)(rbits & 0xffffffffll)) * (N + 2);
+        };
+        auto word_of = [&](int j, int words, int at, int sph) {
+            // word j of a record: the sphere's N + 2 words, then the parameters
+            return (j < words) ? blob[(j < N + 2) ? sph + j : at + j - (N + 2)] : 0.0;
+        };
+        auto put = [&](double *buf, int flags, int words, int m, double t0, double t1) {
+            if (lane < words) buf[2 + lane] = t0;
+            if (lane + 64 < words) buf[2 + 64 + lane] = t1;
+            if (lane == 0) {
+                buf[0] = __longlong_as_double((long long)(unsigned int)flags);         // {flags, param_off 0}
+                buf[1] = __longlong_as_double((long long)m << 32);                     // {-, m}
+            }
+        };
+        if (any != 0ull) {
+            int flags, words, m, at, sph;
+            record_of(__ffsll((long long)any) - 1, flags, words, m, at, sph);
+            const double t0 = word_of(lane, words, at, sph), t1 = word_of(lane + 64, words, at, sph);
+            put(l_par, flags, words, m, t0, t1);
+            cls_lds_sync();
+        }
+        while (any != 0ull) {
+            const int k = __ffsll((long long)any) - 1;
+            any &= any - 1ull;
+            // the next record sets off
+            int n_flags = 0, n_words = 0, n_m = 0, n_at = 0, n_sph = 0;
+            double t0 = 0.0, t1 = 0.0;
+            if (any != 0ull) {
+                record_of(__ffsll((long long)any) - 1, n_flags, n_words, n_m, n_at, n_sph);
+                t0 = word_of(lane, n_words, n_at, n_sph);
+                t1 = word_of(lane + 64, n_words, n_at, n_sph);
+            }
+            const long long rbits = __double_as_longlong(l_ref[k]);
+            const int id = __builtin_amdgcn_readfirstlane((int)(rbits & 0xffffffffll));
+            const int flags = __builtin_amdgcn_readfirstlane((int)(rbits >> 32));
+            const double *rec = l_par + cur * par_stride;
+            bool pass = open && ((want >> k) & 1ull);
+            if ((flags & NDT_F_GATE) && pass) pass = bsphere_gate<N>(rec, sd_par, 0, o, v, min_dist);      // the gate, at its moment
+            if (pass) {
+                double res[N], nrm[N];
+                if (isect<N, false>(rec, sd_par, 0, o, v, res, nrm)) {
+                    const double dist = v_dist<N>(o, res);                                       // object.c:721
+                    if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {         // object.c:722
+                        min_dist = dist;
+                        best = id;
+                    }
+                    if (dist_limit == 0.0 || dist < dist_limit) {                                // object.c:730
+                        open = false;
+                        last = id;          // the scan ends here: the last item it looked at
+                    }
+                }
+            }
+            cur ^= 1;
+            if (any != 0ull) put(l_par + cur * par_stride, n_flags, n_words, n_m, t0, t1);
+            cls_lds_sync();
+            if (__ballot(open) == 0ull) any = 0ull;
+        }
+        cls_lds_sync();
+        // a lane that is still scanning has looked at every item of the window
+        if (open) last = (int)(__double_as_longlong(l_ref[cnt - 1]) & 0xffffffffll);
+        cls_lds_sync();
+    }
+}
 
 // trace_kd (object.c:683) = kd_tree_intersect (kd-tree.c:570-625), with
 //   kd_node_intersect (kd-tree.c:482-568)  unrolled onto an explicit stack,
@@ -934,23 +1205,34 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
 #ifdef NDT_PHASE_TIMING
                       , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
 #endif
-                      , KdStackLds ls = KdStackLds{})
+                      , KdStackLds ls = KdStackLds{}, ClsLds cl = ClsLds{}, const bool has_ray = true, double *box_slot = nullptr)
 {
 #ifdef NDT_PHASE_TIMING
     unsigned long long ph_last = __builtin_readcyclecounter();
 #endif
-    double v_inv[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double v_i = v[i], r;
+    // v_inv of kd_tree_intersect (kd-tree.c:576-590), clamped to +-1/EPS^2.  The LDS tiers keep all N in registers (a tree
+    // step reads one per node).  The global-memory tier -- a ray walks one root-to-leaf path and then scans hundreds of
+    // items -- computes the one it needs at each node instead: N registers (16 in 8-D) the list scan can use.
+    constexpr bool KEEP_INV = (MW != 0);
+    auto inv_of = [](double v_i) {
+        double r;
         if (v_i < NDT_EPS2 && v_i >= 0.0)
             r = NDT_INV_EPS2;
         else if (v_i > -NDT_EPS2 && v_i <= 0.0)
             r = -NDT_INV_EPS2;
         else
             r = 1.0 / v_i;
-        v_inv[i] = r;
+        return r;
+    };
+    double v_inv[N];
+    if (KEEP_INV) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v_inv[i] = inv_of(v[i]);
     }
+    auto inv_at = [&](int dim) {
+        if constexpr (KEEP_INV) return v_pick<N>(v_inv, dim);
+        else return inv_of(v_pick<N>(v, dim));
+    };
     NDT_STAMP(5);
 
     // results
@@ -968,6 +1250,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int node = 0;
     double ntl = 0, ntu = 0;
     bool have_node = false, done = false;
+    bool root_pending = true;       // the root box has not been tested yet
+    bool boxed = false;             // this ray's projections on the scene's box frame are in its LDS slot (item boxes)
 
     // Item sets (MW == 1).  The reference scans a leaf's list in order and skips the items this ray has visited
     // (object.c:707-713).  Lists are ascending in item number, so "the unvisited items of the list, in list order" is
@@ -987,7 +1271,11 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     long long sub_live = -1;                // faces still to scan, bit 0 = the one at sub_i (all ones: every face)
     double sub_min = -1;
 
-    if (sd.n_inf > 0) {
+    if (!has_ray) {
+        // (UNI wavefronts only: a lane without a ray that stays as a helper of the coherent leaf scan)
+        done = true;
+        root_pending = false;
+    } else if (sd.n_inf > 0) {
         // infinite objects first, linear, unmasked (kd-tree.c:594)
         have_list = true;
         list_is_inf = true;
@@ -1004,7 +1292,6 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     // `continue` / `break`): hipcc then emits one structured loop per phase instead of the nest
     // of exec-mask bookkeeping loops it builds for early-continue code, which cost about as many
     // scalar instructions as the arithmetic itself.
-    bool root_pending = true;       // the root box has not been tested yet
     while (true) {
         // ------------------------------------------------------------ phase T
         if (!have_list && !done && root_pending) {
@@ -1063,7 +1350,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         const ndt_v2d prec = blob_pair(blob, sd.off_kd + 2 * parent);
                         const long long pw0 = __double_as_longlong(prec.x);
                         const int pdim = (int)(pw0 & 0xffffffffll);
-                        const double pv_inv = v_pick<N>(v_inv, pdim);
+                        const double pv_inv = inv_at(pdim);
                         a = (prec.y - v_pick<N>(o, pdim)) * pv_inv;
                         nf = (pv_inv < NDT_EPS2) ? parent + 1 : (int)(pw0 >> 32);
                     } else {
@@ -1108,7 +1395,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     }
                 } else {
                     const double boundary = rec.y;
-                    const double v_inv_i = v_pick<N>(v_inv, dim);
+                    const double v_inv_i = inv_at(dim);
                     const double o_i = v_pick<N>(o, dim);
                     // preorder: the left child follows its parent; swap for negative directions
                     const bool swap = v_inv_i < NDT_EPS2;
@@ -1144,13 +1431,46 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             }
         }
         NDT_STAMP(0);
-        if (!have_list) break;      // done
+        // done.  (UNI: a lane whose ray is finished stays with the wavefront until every ray is -- it helps the others fetch
+        // in the coherent leaf scan -- and sits out everything else)
+        if (UNI ? (__ballot(have_list) == 0ull) : !have_list) break;
 
         // ------------------------------------------------------------ phases G + I over the list
         min_dist = -1;
         best_obj = -1;
         best_prim = -1;
-        bool list_open = true;
+        bool list_open = have_list;
+        bool scanned_together = false;
+        if (UNI && MW == 0 && cl.base) {
+            // coherent leaf scan: the lanes that stand on the same leaf (and know what they visited from their history)
+            // scan it together through the wavefront's LDS window, one group of lanes after the other; every lane of the
+            // wavefront -- finished ones too -- helps fetching
+            const bool elig = have_list && !list_is_inf && mask.hist_n >= 0;
+            unsigned long long todo = __ballot(elig);
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int w0 = __builtin_amdgcn_readlane(sec + pos, leader), e0 = __builtin_amdgcn_readlane(sec + end, leader);
+                bool mine = elig && sec + pos == w0;
+                const unsigned long long group = __ballot(mine);
+                todo &= ~group;
+                // Together only when the leaf is shared by many: a wavefront of incoherent rays (shadow rays from scattered
+                // hit points) would scan its leaves one after the other here, where the per-lane scan below does them side by
+                // side -- measured: the mean batch 25-30 % faster with every group scanned together, the slowest twice as slow.
+                if (__popcll(group) < cl.min_group) mine = false;
+                if (__ballot(mine) == 0ull) continue;
+                double md;
+                int best, last;
+                cls_scan<N, MW>(blob, sd, mask, cl.base, mine, o, v, dist_limit, w0, e0, box_slot, boxed, md, best, last);
+                if (mine) {
+                    min_dist = md;
+                    best_obj = best;
+                    best_prim = best;
+                    mask.end_leaf(blob_int(blob, sd.off_kd + 2 * node, 1), last);
+                    list_open = false;
+                    scanned_together = true;
+                }
+            }
+        }
         while (list_open) {
             // ---- phase G: advance to the next primitive that passes its gate
             int prim = -1;
@@ -1180,6 +1500,15 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     auto scan_item = [&](const int id, const int flags, const bool masked) {
                         bool fresh = true;
                         if (masked) fresh = !mask.test_and_set(id);                             // object.c:707-713
+                        // item boxes: a ray that misses the item's box cannot be given a hit by its intersect(); the gate
+                        // and the intersection are skipped, their answer -- nothing -- stands
+                        if (MW == 0 && box_slot && fresh && (flags & NDT_F_OBOX)) {
+                            if (!boxed) {
+                                ray_in_box_frame<N>(blob, sd, o, v, box_slot);
+                                boxed = true;
+                            }
+                            fresh = item_box_meets<N>(blob, sd, id, box_slot);
+                        }
                         if (fresh) {
                             // vect_object_intersect's gate (object.c:618-624), for composites too
                             const double gate_min = in_sub ? sub_min : min_dist;
@@ -1308,14 +1637,17 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
 
         // ---- list finished: what trace() returns to its caller
         NDT_STAMP(3);
+        const bool had_list = have_list;
         have_list = false;
-        if (MW == 0 && !list_is_inf) {
+        if (MW == 0 && had_list && !list_is_inf && !scanned_together) {
             // the leaf's ordinal (its record, which `node` still names) and the last item the scan looked at
             int last, flags_;
             blob_ref(blob, sec + pos - 1, last, flags_);
             mask.end_leaf(blob_int(blob, sd.off_kd + 2 * node, 1), last);
         }
-        if (list_is_inf) {
+        if (!had_list) {
+            // (a finished lane of a UNI wavefront)
+        } else if (list_is_inf) {
             ret_inf = min_dist >= 0;
             if (min_dist > NDT_EPS) t_inf = min_dist;           // object.c:736
             inf_obj = best_obj;

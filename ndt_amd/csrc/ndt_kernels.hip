@@ -330,6 +330,19 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
     }
     VisitMask<MW> mask;
     init_visit_mask<MW>(mask, gblob, sd, ws);
+    // global-memory tier, LDS per wavefront: the rays' projections on the item boxes' frame (N x 64 pairs), then the window
+    // of the coherent leaf scan (ndt_device.hpp:item_box_meets, cls_scan)
+    ClsLds cls{};
+    double *box_slot = nullptr;
+    if (MW == 0 && !LDS) {
+        const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+        const int box_words = sd.off_obox > 0 ? N * 128 : 0;
+        if (sd.off_obox > 0) box_slot = lds_blob + (size_t)wave * box_words + 2 * (threadIdx.x & 63);
+        if (sd.cls_par_words > 0) {
+            cls.base = lds_blob + (size_t)waves * box_words + (size_t)wave * cls_window_words<N>(sd.cls_par_words);
+            cls.min_group = sd.cls_min_group;
+        }
+    }
     const int lane = __lane_id();
     // NDT_HIP_EXIT_PROBE: when does every wavefront start, start its last batch, and run out of work
     const unsigned int probe_start = job.exit_log ? (unsigned int)wall_clock64() : 0u;
@@ -424,6 +437,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         if (b < 0) break;
         if (job.exit_log) probe_batch = (unsigned int)wall_clock64();
         long long g;
+        bool live;
         const bool in_seg = b >= dense_batches;         // wave-uniform
         if (in_seg) {
             // segment of shadow batch sb = number of segments whose inclusive prefix is <= sb
@@ -432,14 +446,18 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
             const int cnt = __shfl(seg_cnt, s, 64);
             const int idx = (sb - first) * bs + lane;
-            if (lane >= bs || idx >= cnt) continue;
-            g = (long long)s * seg_stride + idx;
+            live = lane < bs && idx < cnt;
+            g = (long long)s * seg_stride + (live ? idx : 0);
         } else {
             const long long r = b * bs + lane;
-            if (lane >= bs || r >= dense_count) continue;
-            g = dense_begin + r;
-            if (job.dense.valid && job.dense.valid[g] <= 0) continue;
+            live = lane < bs && r < dense_count;
+            g = dense_begin + (live ? r : 0);
+            if (live && job.dense.valid && job.dense.valid[g] <= 0) live = false;
         }
+        // A lane without a ray.  The LDS tiers leave it out of the batch; in the global-memory tier it stays with the
+        // wavefront as a helper of the coherent leaf scan (ndt_device.hpp:cls_scan: all 64 lanes fetch), with a ray that is
+        // finished before it starts.
+        if (!live && !(MW == 0)) continue;
         const TracePart &part = in_seg ? job.seg : job.dense;
         double o[N], v[N];
 #ifdef NDT_TRACE_SKIP_KNOB
@@ -447,11 +465,14 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             for (int c = 0; c < N; ++c) { o[c] = (double)g; v[c] = 1.0; }
         } else
 #endif
-        {
+        if (live) {
         load_soa<N>(part.o, part.stride, g, o);
         load_soa<N>(part.v, part.stride, g, v);
+        } else {
+#pragma unroll
+            for (int c = 0; c < N; ++c) { o[c] = 0.0; v[c] = 0.0; }
         }
-        const double lim = part.lim ? part.lim[g] : -1.0;
+        const double lim = (live && part.lim) ? part.lim[g] : -1.0;
         int obj, prim;
 #ifdef NDT_PHASE_TIMING
         unsigned int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -462,7 +483,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             obj = (o[0] + v[0] + lim > 1e300) ? 0 : -1;     // keeps the loads alive
             prim = -1;
         } else
-        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
+        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack, cls, live, box_slot);
         out_last = __builtin_readcyclecounter();
         if (ws.dbg && lane == __ffsll((long long)__ballot(1)) - 1) {
             // duration of this batch inside trace_kd: slowest batch of the launch (dbg[40 + is_shadow])
@@ -503,13 +524,15 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             prim = -1;
         } else
 #endif
-        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, kstack, cls, live, box_slot);
 #endif
 #ifdef NDT_TRACE_SKIP_KNOB
         if (job.skip_trace == 2 && obj == -1) continue;
 #endif
-        part.out_obj[g] = obj;
-        part.out_prim[g] = prim;
+        if (live) {
+            part.out_obj[g] = obj;
+            part.out_prim[g] = prim;
+        }
     }
     if (job.exit_log && lane == 0) {
         // one private slot per wavefront: shared counters would serialise the very exits they measure
@@ -636,11 +659,13 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
             NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true>), blocks, block, lds);
         }
     } else {
-        const int res = resident_blocks(k_trace<0, false>, block, 0);
+        // (coherent leaf scan: one LDS window per wavefront)
+        const size_t lds = (size_t)(block / 64) * ((sd.off_obox > 0 ? N * 128 : 0) + (sd.cls_par_words > 0 ? cls_window_words<N>(sd.cls_par_words) : 0)) * sizeof(double);
+        const int res = resident_blocks(k_trace<0, false>, block, lds);
         if (blocks > res) blocks = res;
         const long long max_blocks = ws.mask_slab_lanes / block;
         if (blocks > max_blocks) blocks = max_blocks;
-        NDT_LAUNCH_TRACE((k_trace<0, false>), blocks, block, 0);
+        NDT_LAUNCH_TRACE((k_trace<0, false>), blocks, block, lds);
     }
 }
 

@@ -21,6 +21,7 @@ API_SYMBOLS = [
     "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
     "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
+    "ndt_hip_item_boxes",
 ]
 
 IMAGE_F64, IMAGE_RGBA8 = 0, 1      # enum ndt_image_format
@@ -75,6 +76,7 @@ def load_library():
     lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_device.argtypes = [C.c_void_p]
     lib.ndt_hip_multi_path_taken.argtypes = [C.c_void_p]
+    lib.ndt_hip_item_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = lib
     return lib
@@ -93,6 +95,21 @@ def hcube_hull_box(fs, obj):
     if rc == 0:
         return None
     return rows[:, :n].copy(), rows[:, n].copy(), rows[:, n + 1].copy()
+
+
+def item_boxes(fs):
+    """ndt_hip_item_boxes: (frame [d, d], rows [n_items, d, 2], has [n_items] bool) or None when the scene has no boxed item."""
+    lib = load_library()
+    d, n = fs.dims, fs.struct.n_items
+    frame = np.zeros((d, d))
+    rows = np.zeros((max(n, 1), d, 2))
+    has = np.zeros(max(n, 1), dtype=np.uint8)
+    rc = lib.ndt_hip_item_boxes(fs.byref(), frame.ctypes.data, rows.ctypes.data, has.ctypes.data)
+    if rc < 0:
+        raise NdtHipError(rc, (lib.ndt_hip_last_error() or b"").decode())
+    if rc == 0:
+        return None
+    return frame, rows[:n], has[:n].astype(bool)
 
 
 def hcube_face_boxes(fs, obj):

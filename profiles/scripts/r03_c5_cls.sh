@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, C5: coherent leaf scan on / off, two / one wavefront per SIMD; the tests that pin the tier first.
+cd /root/repo; export TMPDIR=/tmp; O=gpurun_out/${1:-r03b}; mkdir -p $O
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "leaf_history or known_answers or every_pipeline or (full_resolution and hypercube)" > $O/tests_c5.log 2>&1; tail -3 $O/tests_c5.log
+grep -q "failed\|error" $O/tests_c5.log && exit 1
+for w in hypercube6d hypercube7d hypercube8d; do
+  for v in "libndt_hip.so 1" "libndt_hip.so 0" "libndt_hip_clss.so 1"; do
+    set -- $v
+    NDT_HIP_LIB=/root/repo/ndt_amd/$1 NDT_HIP_LEAF_SCAN=$2 timeout -k 10 200 python bench.py --no-cpu-baseline --workload $w --steps 20 --warmup 3 > $O/bench_${w}_$1_$2.log 2>&1 || { tail -5 $O/bench_${w}_$1_$2.log; exit 1; }
+    python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench_${w}_$1_$2.log") if l.startswith("{")][0])
+print("$w $1 leaf_scan=$2", "ms/step %.3f" % d["ms_per_step"], "trace %.3f ms" % d["roofline"]["avg_launch_ms"], "x%g" % d["roofline"]["launches_per_step"], flush=True)
+PY
+  done
+done
