@@ -3,6 +3,7 @@
 // Host code only; compiled with -ffp-contract=off like everything else (the prepare() arithmetic is part of the
 // numerical contract).
 #include "ndt_ctx.hpp"
+#include <algorithm>
 
 extern "C" int ndt_hip_hcube_hull_box(const ndt_flat_scene *fs, int32_t object, double *rows_out)
 {
@@ -914,12 +915,27 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             sd.cls_min_group = ctx->leaf_scan_group;
         }
     }
-    sd.off_oframe = sd.off_obox = 0;
+    sd.off_oframe = sd.off_obox = sd.off_oord = 0;
     if (item_boxes && ctx->tier == 1) {
         sd.off_oframe = b.words();
         for (double x : ib_frame) b.push(x);
+        // per item: its N slabs thinnest first -- a ray that misses a box usually knows after two or three of them -- and
+        // the axis of every slab (4 bits each), so that the ray finds its projection
         sd.off_obox = b.words();
-        for (double x : ib_rows) b.push(x);
+        std::vector<unsigned long long> order((size_t)fs->n_items, 0ull);
+        for (int i = 0; i < fs->n_items; ++i) {
+            int idx[NDT_MAX_DIMS];
+            for (int a = 0; a < n; ++a) idx[a] = a;
+            const double *r = &ib_rows[(size_t)i * 2 * n];
+            std::stable_sort(idx, idx + n, [&](int x, int y) { return r[2 * x + 1] < r[2 * y + 1]; });
+            for (int a = 0; a < n; ++a) {
+                b.push(r[2 * idx[a]]);
+                b.push(r[2 * idx[a] + 1]);
+                order[(size_t)i] |= (unsigned long long)idx[a] << (4 * a);
+            }
+        }
+        sd.off_oord = b.words();
+        for (unsigned long long x : order) b.push_ints((int)(x & 0xffffffffull), (int)(x >> 32));
     }
     sd.total_words = b.words();
 

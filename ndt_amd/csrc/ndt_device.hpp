@@ -65,7 +65,8 @@ struct SceneDesc {
     int cls_par_words;             // > 0: the coherent leaf scan is on; the longest parameter record of a leaf item (even)
     int cls_min_group;             // lanes of a wavefront that must stand on the same leaf to scan it together
     // item boxes (global-memory tier): one orthonormal frame, N x axis[N], and per item N x { centre, half extent }
-    int off_oframe, off_obox;      // off_obox == 0: none
+    int off_oframe, off_obox;      // off_obox == 0: none.  An item's slabs are stored thinnest first ...
+    int off_oord;                  // ... one word per item: the frame axis of its j-th slab in bits 4j .. 4j+3
 };
 
 // ------------------------------------------------------------------ random streams
@@ -759,14 +760,19 @@ template <int N> NDT_DEV void ray_in_box_frame(const double *blob, const SceneDe
 }
 // Ray (t >= 0) against the box of item `id`: false = the ray misses it, so intersect() cannot accept a point of this item
 // (same slab arithmetic as hull_faces, same margin argument); true decides nothing.
+// The slabs come thinnest first, and every second one the wavefront asks whether any of its rays is still inside: a miss is
+// usually known after two or three.
 template <int N> NDT_DEV bool item_box_meets(const double *blob, const SceneDesc &sd, int id, const double *slot)
 {
     const int q = sd.off_obox + id * 2 * N;
+    const unsigned long long ord = (unsigned long long)__double_as_longlong(blob[sd.off_oord + id]);
     double t0 = 0.0, t1 = NDT_DBL_MAX;
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const ndt_v2d pr = *reinterpret_cast<const ndt_v2d *>(slot + k * 128);
+        if (k >= 2 && (k & 1) == 0 && __ballot(ok && t0 <= t1) == 0ull) break;
+        const int axis = (int)((ord >> (4 * k)) & 15ull);
+        const ndt_v2d pr = *reinterpret_cast<const ndt_v2d *>(slot + axis * 128);
         const ndt_v2d box = blob_pair(blob, q + 2 * k);
         const double a = pr.x - box.x, h = box.y;
         if (pr.y == 0.0) {
@@ -970,9 +976,9 @@ struct ClsLds {
     double *base;       // this wavefront's window; nullptr = off
     int min_group;      // lanes that must share a leaf for the scan to be done together
 };
-// 64 entries, 64 x {param_off, words | m << 16}, 64 x 2N words (an item's box rows, or its bounding sphere when it has no
+// 64 entries, 64 x {param_off, words | m << 16}, 64 axis orders, 64 x 2N words (an item's box rows, or its bounding sphere when it has no
 // box), two records (2 header words + the sphere + par_words of parameters each)
-template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words); }
+template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words); }
 #define NDT_CLS_MAX_PAR_WORDS (128 - 12)     /* sphere + parameters are fetched as two words per lane (N <= 10) */
 
 NDT_DEV void cls_lds_sync()
@@ -994,10 +1000,11 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
                       double *box_slot, bool &boxed, double &min_dist, int &best, int &last)
 {
     const int lane = __lane_id();
-    double *l_ref = win, *l_inf = win + 64, *l_win = win + 128, *l_par = win + 128 + 64 * 2 * N;
+    double *l_ref = win, *l_inf = win + 64, *l_ord = win + 128, *l_win = win + 192, *l_par = win + 192 + 64 * 2 * N;
     const int par_stride = 2 + N + 2 + sd.cls_par_words;
     SceneDesc sd_win = sd;      // item_box_meets / bsphere_gate on the window: item k's 2N words at k * 2N
     sd_win.off_obox = 0;
+    sd_win.off_oord = -64;      // the items' axis orders sit right in front of the window's rows
     SceneDesc sd_par = sd;      // a staged record: header at words 0 .. 1, the sphere at 2, parameters behind it
     sd_par.off_hdr = 0;
     sd_par.off_bs = 2;
@@ -1034,6 +1041,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
                 }
             }
             l_ref[lane] = ref;
+            if (has_box) l_ord[lane] = blob[sd.off_oord + id];
             const long long h0 = __double_as_longlong(hdr.x), h1 = __double_as_longlong(hdr.y);
             l_inf[lane] = __longlong_as_double(((h0 >> 32) & 0xffffffffll) | (((h1 & 0xffffll) | ((h1 >> 32) << 16)) << 32));
 #pragma unroll
@@ -1447,6 +1455,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             // wavefront -- finished ones too -- helps fetching
             const bool elig = have_list && !list_is_inf && mask.hist_n >= 0;
             unsigned long long todo = __ballot(elig);
+            const int n_listed = __popcll(__ballot(have_list));
             while (todo != 0ull) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const int w0 = __builtin_amdgcn_readlane(sec + pos, leader), e0 = __builtin_amdgcn_readlane(sec + end, leader);
@@ -1456,7 +1465,9 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 // Together only when the leaf is shared by many: a wavefront of incoherent rays (shadow rays from scattered
                 // hit points) would scan its leaves one after the other here, where the per-lane scan below does them side by
                 // side -- measured: the mean batch 25-30 % faster with every group scanned together, the slowest twice as slow.
-                if (__popcll(group) < cl.min_group) mine = false;
+                // (a batch that is not full -- a frame's last, lanes whose rays are finished -- counts as whole when all the
+                // rays it still has stand on the leaf)
+                if (__popcll(group) < cl.min_group && !(__popcll(group) == n_listed && n_listed >= 16)) mine = false;
                 if (__ballot(mine) == 0ull) continue;
                 double md;
                 int best, last;
