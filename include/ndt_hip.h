@@ -32,7 +32,7 @@ extern "C" {
 /* Dimensions the gfx950 kernels are instantiated for.  The reference accepts any N >= 3
  * (ndt.c:1450 `-d`); BASELINE.json's configs span 3..8. */
 #define NDT_MIN_DIMS 3
-#define NDT_MAX_DIMS 8
+#define NDT_MAX_DIMS 10
 #define NDT_MAX_LIGHTS 64
 
 #define NDT_OK              0
@@ -295,6 +295,8 @@ int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
  *   "leaf_history"            scenes in the global-memory tier (more than 256 items): a ray remembers what it visited as up to
  *                                this many {leaf, cut} pairs (default and maximum 4) before it falls back to its bit mask in
  *                                the slab; 0: the slab only (tests prove every value neutral)
+ *   "sample_seed"     stochastic renders (-n > 1, area lights): which set of counter-based random streams the samples draw
+ *                     from (0, the default, and any other value give images that are independent draws of one distribution)
  *   "multi_path"      ndt_hip_render_multi: 0 auto (stores on the same device, peer stores over xGMI, a staged copy where
  *                     there is no peer access), 1 never staged, 2 always staged -- also between contexts of one device
  *   "shade_pair"      0: lighting of a bounce and shading of the next as two launches

@@ -102,6 +102,7 @@ struct ndt_hip_ctx {
     size_t d_stage_bytes = 0;
     hipStream_t stage_stream = nullptr;
     int stage_device = 0;
+    long long sample_seed = 0;      // option "sample_seed": selects the set of random streams of the stochastic paths (0: the default set)
     int multi_path = 0;             // option "multi_path": 0 auto, 1 never staged, 2 always staged
     int multi_path_taken = 0;       // ndt_multi_path of the last multi-context frame (ndt_hip_multi_path_taken)
     ndt_impl::CtxWorker *worker = nullptr;

@@ -23,7 +23,7 @@
 #include <tuple>
 
 #ifndef NDT_DIMS
-#error "compile with -DNDT_DIMS=<3..8>"
+#error "compile with -DNDT_DIMS=<3..10>"
 #endif
 #define NDT_CAT2(a, b) a##b
 #define NDT_CAT(a, b) NDT_CAT2(a, b)

@@ -207,6 +207,8 @@ extern "C" const NdtKernelTable *ndt_kernel_table_5();
 extern "C" const NdtKernelTable *ndt_kernel_table_6();
 extern "C" const NdtKernelTable *ndt_kernel_table_7();
 extern "C" const NdtKernelTable *ndt_kernel_table_8();
+extern "C" const NdtKernelTable *ndt_kernel_table_9();
+extern "C" const NdtKernelTable *ndt_kernel_table_10();
 
 #define NDT_TRACE_BLOCK 256
 // The global-memory tier (visit masks in the slab, scene in global memory: the 6-D .. 8-D hypercubes) launches

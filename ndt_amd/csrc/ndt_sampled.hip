@@ -20,7 +20,8 @@ __device__ __forceinline__ unsigned long long ns_sample_key(unsigned long long p
 // sample r of the active pixels: (i + dx, j - dy) and the lens offsets (ndt.c:505-514, 527-541)
 // (`per` consecutive samples per pixel in one pass: sample a*per + r is the pixel's sample number round + r)
 __global__ void k_ns_samples(const int *active, int n_active, int per, int width, int row_begin, int row_step, unsigned int round0,
-                             double aperture, int jitter, double xs, double ys, double *samples, unsigned long long *keys)
+                             double aperture, int jitter, double xs, double ys, double *samples, unsigned long long *keys,
+                             unsigned long long seed)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= (long long)n_active * per) return;
@@ -29,7 +30,9 @@ __global__ void k_ns_samples(const int *active, int n_active, int per, int width
     const int l = pix / width, i = pix % width;
     const int j = row_begin + l * row_step;
     const unsigned long long id = (unsigned long long)j * (unsigned long long)width + (unsigned long long)i;
-    const unsigned long long key = ns_sample_key(id, round);
+    // (seed: option "sample_seed", 0 by default -- another value is another, independent set of streams: what the tests use to
+    // draw an ENSEMBLE of device images and compare it with the oracle's, two samples of the same distribution)
+    const unsigned long long key = ns_sample_key(id, round) ^ ndt_rng_mix(seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull) * (seed != 0ull);
     keys[a] = key;
     double dx = 0.0, dy = 0.0, ax = 0.0, ay = 0.0;
     if (jitter) {       // -n > 1 only (ndt.c:505, 528); with -n 1 the area lights are all that is random
@@ -155,7 +158,8 @@ int ndt_impl::render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void 
         const unsigned g_act = (unsigned)((n_active + 255) / 256);
         hipLaunchKernelGGL(k_ns_samples, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, list[flip], n_active, (int)per, W,
                            p->row_begin, p->row_step, round, ctx->aperture_radius, p->samples > 1 ? 1 : 0,
-                           p->stereo == NDT_STEREO_SIDE_SIDE ? 0.5 : 1.0, p->stereo == NDT_STEREO_OVER_UNDER ? 0.5 : 1.0, samples, keys);
+                           p->stereo == NDT_STEREO_SIDE_SIDE ? 0.5 : 1.0, p->stereo == NDT_STEREO_OVER_UNDER ? 0.5 : 1.0, samples, keys,
+                           (unsigned long long)ctx->sample_seed);
         RenderGeom gs{};
         gs.samples = samples;
         gs.n_samples = (int)n_s;

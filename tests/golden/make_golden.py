@@ -48,6 +48,12 @@ CASES = {
     "c5_hypercube6d": dict(scene="hypercube", dims=6, res=(48, 27), depth=128, fb=True, kat=512),
     "c5_hypercube7d": dict(scene="hypercube", dims=7, res=(32, 18), depth=128, fb=True, kat=256),
     "c5_hypercube8d": dict(scene="hypercube", dims=8, res=(24, 14), depth=128, fb=True, kat=128),
+    # beyond BASELINE's sweep (the reference takes any -d >= 3, ndt.c:1499-1503): 9-D and 10-D.  The zoo (every type; its
+    # hcube has 16 866 / 52 904 nested faces there) and the 9-D hypercube (19 682 objects, 1025 kd nodes).  (random.c's four
+    # hcubes make a 12 MB / 42 MB scene file in 9-D / 10-D and its camera sees none of it: not kept.)
+    "zoo9d": dict(scene="parity_zoo", dims=9, res=(40, 24), depth=5, fb=True, kat=512),
+    "zoo10d": dict(scene="parity_zoo", dims=10, res=(40, 24), depth=5, fb=True, kat=512),
+    "c5_hypercube9d": dict(scene="hypercube", dims=9, res=(24, 14), depth=128, fb=True, kat=1024, kat_aimed=True),
     # tests/scenes/parity_zoo.c (this repo's own scene program, compiled against the reference):
     # spot light, LIGHT_AMBIENT entry + scn->ambient, glass with total internal reflection, finite
     # hcylinder, infinite cylinder, computed-normal hfacet, skewed hcube, rotated cluster
