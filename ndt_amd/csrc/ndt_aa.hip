@@ -124,7 +124,28 @@ __global__ void k_aa_resolve(const AaTask *tasks, int n_tasks, int leaf, AaTask 
     for (int c = 0; c < 4; ++c) dst[c] = res[c];
 }
 
-int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total)
+// the depth map beside an anti-aliased image (ndt.c:930-935, 753-756): the first pass's depths; the corner samples of the
+// last column and row fall outside the width x height map (image.c:126 checks the bounds)
+__global__ void k_aa_depth_crop(const double *pass1_depth, int width, int rows, int row_pair, double *out)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * width) return;
+    const int l = (int)(idx / width), i = (int)(idx % width);
+    out[idx] = pass1_depth[(long long)(row_pair ? 2 * l : l) * (width + 1) + i];
+}
+
+// the first pass's corner samples as a position list: sample (r, i) of the (width) x (rows) grid is image position
+// (i, row_begin + r * row_step), or with row pairs (row_begin + (r / 2) * row_step + r % 2)
+__global__ void k_aa_corner_positions(double *pos, int width, int rows, int row_begin, int row_step, int row_pair)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * width) return;
+    const int r = (int)(idx / width), i = (int)(idx % width);
+    pos[2 * idx] = i;
+    pos[2 * idx + 1] = row_pair ? row_begin + (r >> 1) * row_step + (r & 1) : row_begin + r * row_step;
+}
+
+int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total, void *d_depth)
 {
     hipStream_t s = ctx->stream;
     const bool prof = p->profile != 0;
@@ -132,6 +153,57 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
     const int rows = ndt_hip_shard_rows(H, p->row_begin, p->row_step);
     AaBuffers buf(ctx);
     int rc;
+    // One pass of the ray pipeline for this image's samples: render_pixel (ndt.c:578-653) for every one of them -- the image
+    // split of side-by-side / over-under by the sample's position, or, for an anaglyph, BOTH eyes and their mix (ndt.c:636-647):
+    // the anti-aliasing works on the mixed colours (its subdivision tests see red = left luminance, blue = right luminance).
+    // With a lens (aperture_radius != 0), area lights or -n > 1 a sample is not one ray tree but get_pixel_color's whole
+    // adaptive loop over random ones -- the reference samples the lens in this mode too (ndt.c:528: `recursive_aa != 0 ||
+    // samples > 1`; the jitter stays off, ndt.c:505) -- and the anti-aliasing, its subdivision tests included, runs on those
+    // noisy colours: a stochastic render.  The samples then go through the sampled renderer as a list of positions.
+    const bool stochastic = ctx->aperture_radius != 0.0 || ctx->has_area_lights || p->samples > 1;
+    auto pass = [&](RenderGeom g, double *out, long long n_out, double *depth_out, ndt_render_stats &st) -> int {
+        st = ndt_render_stats{};
+        if (stochastic) {
+            int r;
+            const double *pos = g.samples;
+            if (!pos) {
+                // the first pass's corner grid as positions
+                double *grid = nullptr;
+                if ((r = buf.get(&grid, (size_t)n_out * 2))) return r;
+                hipLaunchKernelGGL(k_aa_corner_positions, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, grid, g.width, g.rows,
+                                   g.row_begin, g.row_step, g.row_pair);
+                pos = grid;
+            }
+            SampledList sl{ pos, n_out, g.img_w, g.img_h, g.aspect_w, g.aspect_h };
+            if (p->stereo != NDT_STEREO_ANAGLYPH) return render_sampled_list(ctx, p, sl, 1, p->stereo, 0ull, out, st);
+            double *left = nullptr, *right = nullptr;
+            if ((r = buf.get(&left, (size_t)n_out * 4))) return r;
+            if ((r = buf.get(&right, (size_t)n_out * 4))) return r;
+            if ((r = render_sampled_list(ctx, p, sl, 0, 0, 0ull, left, st))) return r;
+            if ((r = render_sampled_list(ctx, p, sl, 2, 0, 0x5eed0000000000ffull, right, st))) return r;
+            launch_anaglyph(s, left, right, out, n_out);
+            return NDT_OK;
+        }
+        if (p->stereo != NDT_STEREO_ANAGLYPH) {
+            g.stereo = p->stereo;
+            g.eye = 1;
+            return render_pass(ctx, g, prof, out, st, depth_out);
+        }
+        double *left = nullptr, *right = nullptr;
+        int r;
+        if ((r = buf.get(&left, (size_t)n_out * 4))) return r;
+        if ((r = buf.get(&right, (size_t)n_out * 4))) return r;
+        ndt_render_stats one{};
+        g.stereo = 0;
+        g.eye = 0;
+        if ((r = render_pass(ctx, g, prof, left, one, depth_out))) return r;        // (the depth map is the left eye's, ndt.c:640)
+        add_stats(st, one);
+        g.eye = 2;
+        if ((r = render_pass(ctx, g, prof, right, one))) return r;
+        add_stats(st, one);
+        launch_anaglyph(s, left, right, out, n_out);
+        return NDT_OK;
+    };
     // ---- first pass: the corner rows this shard touches, (W+1) wide (ndt.c:919-976)
     RenderGeom g1{};
     g1.width = W + 1;
@@ -150,13 +222,15 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
     g1.img_h = H + 1;
     g1.aspect_w = W;
     g1.aspect_h = H;
-    g1.eye = 1;
-    g1.stereo = p->stereo;          // side-by-side / over-under: every sample is split by its position (ndt.c:590-612), in the (W+1) x (H+1) frame
-    double *pass1 = nullptr;
+    double *pass1 = nullptr, *pass1_depth = nullptr;
     if ((rc = buf.get(&pass1, (size_t)g1.rows * g1.width * 4))) return rc;
+    if (d_depth && (rc = buf.get(&pass1_depth, (size_t)g1.rows * g1.width))) return rc;
     ndt_render_stats st{};
-    if ((rc = render_pass(ctx, g1, prof, pass1, st))) return rc;
+    if ((rc = pass(g1, pass1, (long long)g1.rows * g1.width, pass1_depth, st))) return rc;
     add_stats(total, st);
+    if (d_depth)
+        hipLaunchKernelGGL(k_aa_depth_crop, dim3((unsigned)(((long long)rows * W + 255) / 256)), dim3(256), 0, s, pass1_depth, W, rows,
+                           g1.row_pair, (double *)d_depth);
 
     // ---- second pass
     const double threshold = p->aa_diff / 255.0;
@@ -204,9 +278,7 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
         gs.img_h = H + 1;
         gs.aspect_w = W;
         gs.aspect_h = H;
-        gs.eye = 1;
-        gs.stereo = p->stereo;
-        if ((rc = render_pass(ctx, gs, prof, colours, st))) return rc;
+        if ((rc = pass(gs, colours, gs.n_samples, nullptr, st))) return rc;
         add_stats(total, st);
         total.aa_samples += gs.n_samples;
         hipLaunchKernelGGL(k_aa_split, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, s, level_tasks[L], n_tasks, step, threshold,

@@ -112,6 +112,8 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     if (ctx->d_image) (void)hipFree(ctx->d_image);
     for (auto &slot : ctx->pool)
         if (slot.first) (void)hipFree(slot.first);
+    for (auto &slot : ctx->pool2)
+        if (slot.first) (void)hipFree(slot.first);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);

@@ -61,6 +61,7 @@ struct ndt_hip_ctx {
     std::vector<void *> ws_allocs;
     std::vector<void *> sa_allocs;                  // the frame kernel's queues and counters (ensure_stream_args)
     std::vector<std::pair<void *, size_t>> pool;    // scratch of the multi-pass renderers (AaBuffers)
+    std::vector<std::pair<void *, size_t>> pool2;   // ... of a sampled render nested in an anti-aliased one
     long long ws_dims = 0;
     long long ws_slab_words = 0;
     int ws_nseg = 0;
@@ -144,8 +145,19 @@ void worker_stop(ndt_hip_ctx *ctx);
 void free_stage(ndt_hip_ctx *ctx);
 
 // ndt_aa.hip / ndt_sampled.hip
-int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);
-int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total);
+int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total, void *d_depth = nullptr);
+// ndt_render.hip: true anaglyph (ndt.c:643-647) of two eye images, n_pixels x rgba each
+void launch_anaglyph(hipStream_t s, const double *left, const double *right, double *out, long long n_pixels);
+int render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total, void *d_depth = nullptr);
+// get_pixel_color's adaptive loop (ndt.c:488-568) for a LIST of image positions (2 doubles each, pixels of an img_w x img_h
+// image): the samples of a stochastic anti-aliased render (a lens, area lights).  No jitter (ndt.c:505: not in this mode).
+struct SampledList {
+    const double *d_pos;
+    long long n_pos;
+    int img_w, img_h, aspect_w, aspect_h;
+};
+int render_sampled_list(ndt_hip_ctx *ctx, const ndt_render_params *p, const SampledList &sl, int eye, int stereo, unsigned long long salt,
+                        void *d_rgba, ndt_render_stats &total);
 
 // One slot of a device-side list for every lane that wants one, with ONE atomic per wavefront (a counter serves ~150
 // returning atomics per us: a list appended to by every thread of a 2-million-thread launch queues for milliseconds).
@@ -167,13 +179,14 @@ __device__ __forceinline__ int wave_append(int *counter, bool want)
 // which synchronises the device.
 struct AaBuffers {
     ndt_hip_ctx *ctx;
+    std::vector<std::pair<void *, size_t>> *from;
     size_t next = 0;
-    explicit AaBuffers(ndt_hip_ctx *c) : ctx(c) {}
+    explicit AaBuffers(ndt_hip_ctx *c, bool nested = false) : ctx(c), from(nested ? &c->pool2 : &c->pool) {}
     template <typename T> int get(T **ptr, size_t count)
     {
         const size_t bytes = (count > 0 ? count : 1) * sizeof(T);
-        if (next == ctx->pool.size()) ctx->pool.push_back({ nullptr, 0 });
-        auto &slot = ctx->pool[next++];
+        if (next == from->size()) from->push_back({ nullptr, 0 });
+        auto &slot = (*from)[next++];
         if (slot.second < bytes) {
             if (slot.first) {
                 (void)hipStreamSynchronize(ctx->stream);

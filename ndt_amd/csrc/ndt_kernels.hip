@@ -130,7 +130,7 @@ NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspa
         return false;
     }
     // (jittered samples: the PIXEL decides the half, the jitter comes after -- i + dx/2 and j - dy/2 lie in [i, i+1) and (j-1, j])
-    const double half_i = rg.raw_samples ? floor(ip) : ip, half_j = rg.raw_samples ? ceil(jp) : jp;
+    const double half_i = rg.pixel_halves ? floor(ip) : ip, half_j = rg.pixel_halves ? ceil(jp) : jp;
     if (rg.stereo == 1) {           // SIDE_SIDE_3D, x_scale = 0.5 (ndt.c:591-601)
         if (half_i < rg.img_w / 2) { ip = ip / 0.5; eye = 0; }
         else { ip = (ip - rg.img_w / 2) / 0.5; eye = 2; }
@@ -141,9 +141,10 @@ NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspa
     double y_div = (double)rg.img_h;
     if (rg.stereo == 4) {           // HIDEF_3D frame packing (ndt.c:614-631): 1080 lines left eye, 45 blank, 1080 right eye
         y_div = 1080.0;
-        if (jp < 1080) {
+        // (jittered samples: the PIXEL's row decides, as for the halves above)
+        if (half_j < 1080) {
             eye = 0;
-        } else if (jp > 1080 + 45) {
+        } else if (half_j > 1080 + 45) {
             jp = jp - (1080 + 45);
             eye = 2;
         } else {

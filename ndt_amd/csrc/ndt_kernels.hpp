@@ -73,6 +73,7 @@ struct RenderGeom {
     int n_samples;
     int lens;                   // list mode: records are (i, j, lx, ly): the eye is moved by lx*localX + ly*localY (ndt.c:538-541)
     int raw_samples;            // list mode: one colour per sample as traced (-n > 1), no replay of the samples=1 loop
+    int pixel_halves;           // list mode: the samples are jittered pixels -- the PIXEL decides the half / the eye of a split image
     const unsigned long long *sample_keys;  // list mode, stochastic renders: the random stream of every sample
     int stereo;                 // ndt_stereo_mode: 1 side by side, 2 over/under split the image between the eyes (ndt.c:590-612)
     int eye;                    // 0 left, 1 centre, 2 right: the eye when stereo does not split the image (anaglyph renders twice)

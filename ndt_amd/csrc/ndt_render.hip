@@ -14,6 +14,12 @@ __global__ void k_anaglyph(const double *left, const double *right, double *out,
     out[4 * i + 3] = 1.0;
 }
 
+void ndt_impl::launch_anaglyph(hipStream_t s, const double *left, const double *right, double *out, long long n_pixels)
+{
+    if (n_pixels <= 0) return;
+    hipLaunchKernelGGL(k_anaglyph, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, left, right, out, n_pixels);
+}
+
 extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, void *d_depth,
                                            ndt_render_stats *stats)
 {
@@ -21,8 +27,10 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (!ctx->have_scene) return fail(NDT_E_STATE, "no scene uploaded");
     if (p->samples < 1) return fail(NDT_E_INVALID, "samples=%d", p->samples);
     const bool stochastic = p->samples > 1 || ctx->has_area_lights;
-    if (stochastic && (p->recursive_aa || d_depth || (p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)))
-        return fail(NDT_E_UNSUPPORTED, "samples > 1 and area lights are implemented for mono, side-by-side and over/under images without recursive anti-aliasing or a depth map");
+    // (a stochastic anti-aliased render -- a lens, area lights or -n > 1 under -a -- has no depth map here: the map would be
+    // the last lens sample's of every first-pass corner)
+    if (p->recursive_aa && d_depth && (stochastic || ctx->aperture_radius != 0.0))
+        return fail(NDT_E_UNSUPPORTED, "no depth map beside a stochastic anti-aliased render (lens, area lights or samples > 1 with recursive_aa)");
     if (p->samples > 1 && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
         return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0) return fail(NDT_E_INVALID, "bad geometry");
@@ -30,11 +38,13 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     if (p->stereo != NDT_STEREO_MONO && !ctx->have_eyes) return fail(NDT_E_INVALID, "stereo needs leftEye / rightEye (camera.h:60-61) in the flat scene");
     for (int k = 0; k < 4; ++k)
         if (p->reserved[k] != 0) return fail(NDT_E_INVALID, "reserved render parameter set");
-    if (p->recursive_aa && ctx->aperture_radius != 0.0)
-        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing with aperture radius %g samples the lens with drand48 (ndt.c:528): not reproducible", ctx->aperture_radius);
+    if (p->recursive_aa && ctx->aperture_radius != 0.0 && !ctx->have_local_axes)
+        return fail(NDT_E_INVALID, "depth of field needs the camera's local axes (camera.h:69-71) in the flat scene");
     if (p->recursive_aa && (p->aa_diff < 0 || p->aa_depth > 24)) return fail(NDT_E_INVALID, "bad anti-aliasing parameters");
-    if (p->recursive_aa && ((p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER) || d_depth))
-        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing is implemented for mono, side-by-side and over/under images without a depth map");
+    // (the reference's recursive_resample averages the alpha of its samples, and the samples that fall on the 45 blank lines
+    // of a frame-packed image come back with an alpha nobody set, ndt.c:662, 625-627: there is nothing to be equal to)
+    if (p->recursive_aa && p->stereo == NDT_STEREO_HIDEF)
+        return fail(NDT_E_UNSUPPORTED, "recursive anti-aliasing of a frame-packed image reads uninitialised alpha in the reference (ndt.c:662)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
@@ -56,9 +66,9 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
     int rc;
     // the reference's switch: -a with depth >= 0 and diff < 256 resamples, otherwise the first pass is copied (ndt.c:1040)
     if (p->recursive_aa) {
-        rc = render_antialiased(ctx, p, d_rgba, st);
+        rc = render_antialiased(ctx, p, d_rgba, st, d_depth);
     } else if (stochastic) {
-        rc = render_sampled(ctx, p, d_rgba, st);
+        rc = render_sampled(ctx, p, d_rgba, st, d_depth);
     } else {
         RenderGeom rg{};
         rg.width = p->width;
@@ -91,7 +101,7 @@ extern "C" int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_pa
             rg.eye = 2;
             if ((rc = render_pass(ctx, rg, p->profile != 0, right, one))) return rc;
             add_stats(st, one);
-            hipLaunchKernelGGL(k_anaglyph, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, left, right, (double *)d_rgba, n_pixels);
+            launch_anaglyph(s, left, right, (double *)d_rgba, n_pixels);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(s));
             rc = NDT_OK;

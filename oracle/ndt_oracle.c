@@ -1000,6 +1000,7 @@ typedef struct {
     int specular;
     int samples;            /* `-n`: > 1 = jittered samples + lens sampling with drand48 (ndt.c:505-542) */
     int stochastic;         /* samples > 1 or area lights: every pass of the adaptive loop is a different ray tree */
+    int aa_lens;            /* recursive anti-aliasing with an aperture: every sample draws a lens point (ndt.c:528) */
     double pix_w, pix_h;    /* 1/width, 1/height of the image being rendered (ndt.c:482-483) */
 } tctx;
 
@@ -1336,9 +1337,10 @@ static void get_pixel_color_m(tctx *T, double x, double y, pix *clr, int max_opt
                 double azi = x * S->fs->cam_h_fov;
                 v_rotate2(virtCam, S->cam_pos, S->cam_local_x, S->cam_local_z, azi, virtCam, n);
             }
-            if (samples > 1) {
-                /* lens sample for depth of field (ndt.c:527-542): rejection in the unit disk, also drawn
-                 * when the aperture is 0 (the offsets are then zero vectors) */
+            if (samples > 1 || T->aa_lens) {
+                /* lens sample for depth of field (ndt.c:527-542: `recursive_aa != 0 || samples > 1`): rejection in the unit
+                 * disk, also drawn when the aperture is 0 (the offsets are then zero vectors; in the anti-aliasing mode the
+                 * draws are then skipped here -- nothing else reads the stream) */
                 double ax, ay;
                 do {
                     ax = 2 * drand48() - 1.0;
@@ -1471,6 +1473,7 @@ static void tctx_open(tctx *T, job *J)
     T->specular = J->p->specular;
     T->samples = J->p->samples;
     T->stochastic = J->stochastic;
+    T->aa_lens = J->p->recursive_aa && J->S->fs->cam_aperture_radius != 0.0;
     T->pix_w = 1.0 / (J->p->width + (J->p->recursive_aa ? 1 : 0));
     T->pix_h = 1.0 / (J->p->height + (J->p->recursive_aa ? 1 : 0));
 }
@@ -1563,11 +1566,17 @@ static void *render_corner_rows(void *arg)
     for (int r = 0; r < J->n1; ++r) {
         if (r % J->threads != J->thr)
             continue;
+        /* the depth map of an anti-aliased render (ndt.c:930-935, 753-756): the first pass's depths; the map is width x height,
+         * the corner samples of column `width` and row `height` fall outside and are dropped (image.c:126: bounds check) */
+        const int j = J->row_of[r];
+        const int local = (j >= p->row_begin && (j - p->row_begin) % p->row_step == 0 && j < p->height) ? (j - p->row_begin) / p->row_step : -1;
+        double depth = 0.0;
         for (int i = 0; i < w1; ++i) {
             pix clr;
-            render_pixel(J, &T, w1, h1, i, J->row_of[r], &clr);
+            render_pixel_d(J, &T, w1, h1, i, j, &clr, J->depth ? &depth : NULL);
             double *out = img + ((size_t)r * w1 + i) * 4;
             out[0] = clr.r; out[1] = clr.g; out[2] = clr.b; out[3] = clr.a;
+            if (J->depth && local >= 0 && i < p->width) J->depth[(size_t)local * p->width + i] = depth;
         }
     }
     J->cnt = T.cnt;
@@ -1627,17 +1636,17 @@ static int check_supported(const ndt_flat_scene *fs, const ndt_render_params *p)
     }
     if (p && (p->samples < 1 || p->width < 1 || p->height < 1 || p->row_step < 1 || p->row_begin < 0))
         return NDT_E_INVALID;
-    /* samples > 1: jitter + lens sampling from drand48 (ndt.c:505-542); not combined with the other modes here */
-    if (p && p->samples > 1 && (p->recursive_aa || (p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)))
-        return NDT_E_UNSUPPORTED;
+    /* samples > 1: jitter + lens sampling from drand48 (ndt.c:505-542), in every stereo mode and with a depth map; with
+     * recursive anti-aliasing on top (no jitter, `samples` lens samples per anti-aliasing sample) it is not pinned by fixtures */
+    if (p && p->samples > 1 && p->recursive_aa) return NDT_E_UNSUPPORTED;
     if (p && p->samples > 1 && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
     if (p && (p->stereo < NDT_STEREO_MONO || p->stereo > NDT_STEREO_HIDEF)) return NDT_E_UNSUPPORTED;
-    /* recursive AA with the modes that split the image (render_pixel does the split for every sample, ndt.c:590-612);
-     * anaglyph and frame packing with AA are not pinned by fixtures */
-    if (p && p->recursive_aa && p->stereo != NDT_STEREO_MONO && p->stereo != NDT_STEREO_SIDE_SIDE && p->stereo != NDT_STEREO_OVER_UNDER)
-        return NDT_E_UNSUPPORTED;
-    /* recursive AA samples the aperture with drand48 (ndt.c:528-542): deterministic only for a pinhole */
-    if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0) return NDT_E_UNSUPPORTED;
+    /* recursive AA: render_pixel does the image split / the two eyes of an anaglyph for every sample (ndt.c:590-650).  Not
+     * frame packing: the samples that fall on the 45 blank lines come back with an alpha recursive_resample never set
+     * (ndt.c:662: p5 .. p9 are uninitialised) and it averages them in */
+    if (p && p->recursive_aa && p->stereo == NDT_STEREO_HIDEF) return NDT_E_UNSUPPORTED;
+    /* (recursive AA with a lens: every sample draws its lens point from drand48, ndt.c:528-542 -- a stochastic render) */
+    if (p && p->recursive_aa && fs->cam_aperture_radius != 0.0 && (fs->cam_local_x_off < 0 || fs->cam_local_y_off < 0)) return NDT_E_INVALID;
     return NDT_OK;
 }
 
@@ -1686,6 +1695,7 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
     int stochastic = p->samples > 1;
     for (int i = 0; i < fs->n_lights; ++i)
         if (fs->lights[i].type == NDT_LIGHT_DISK || fs->lights[i].type == NDT_LIGHT_RECT) stochastic = 1;
+    if (p->recursive_aa && fs->cam_aperture_radius != 0.0) stochastic = 1;     /* the lens is sampled in this mode too (ndt.c:528) */
     if (stochastic) {
         /* the random numbers come from one global stream in pixel order: one thread, starting where the
          * reference run that made the fixture stood (ndt_oracle_set_seed48) */
@@ -1707,11 +1717,6 @@ int ndt_oracle_render_depth(const ndt_flat_scene *fs, const ndt_render_params *p
     ray_counts cnt1 = { 0, 0, 0 };
     double *pass1 = NULL;
     int *row_of = NULL;
-    if (depth && p->recursive_aa) {
-        free(jobs);
-        free_scene(&S);
-        return NDT_E_UNSUPPORTED;
-    }
     if (!p->recursive_aa) {
         run_jobs(jobs, threads, render_rows);
     } else {

@@ -387,9 +387,33 @@ int main(int argc, char **argv)
         double t0 = now_s();
         /* the stereo modes that split the image (ndt.c:913-916): render_image hands mode and scales to both passes */
         const double aa_xs = stereo == 1 ? 0.5 : 1.0, aa_ys = stereo == 2 ? 0.5 : 1.0;
-        if (stereo != 0 && stereo != 1 && stereo != 2) { fprintf(stderr, "ref_shim: --aa with --stereo %d is not wired\n", stereo); return 2; }
+        /* (frame packing, stereo 4, is left out: recursive_resample averages the never-set alpha of its blank-line samples) */
+        if (stereo < 0 || stereo > 3) { fprintf(stderr, "ref_shim: --aa with --stereo %d is not wired\n", stereo); return 2; }
+        {
+            /* with an aperture every sample draws its lens point from the *rand48 stream (ndt.c:528): where it stands */
+            unsigned short probe[3] = { 0, 0, 0 }, keep[3];
+            unsigned short *old = seed48(probe);
+            keep[0] = old[0]; keep[1] = old[1]; keep[2] = old[2];
+            seed48(keep);
+            printf("ref_shim: seed48 %u %u %u\n", keep[0], keep[1], keep[2]);
+        }
+        /* the depth map render_image makes beside an anti-aliased image: width x height, filled by the first pass
+         * (ndt.c:930-935, 753-756; the corner samples of the last column and row fall outside it) */
+        image_t aa_depth_img;
+        if (depth_out) {
+            dbl_image_init(&aa_depth_img);
+            image_set_size(&aa_depth_img, width, height);
+        }
         for (int j = 0; j < height + 1; ++j)
-            render_line(&scn, width + 1, aa_xs, height + 1, aa_ys, j, stereo, 1, &img, NULL, max_depth);
+            render_line(&scn, width + 1, aa_xs, height + 1, aa_ys, j, stereo, 1, &img, depth_out ? &aa_depth_img : NULL, max_depth);
+        if (depth_out) {
+            FILE *f = fopen(depth_out, "wb");
+            if (!f) { perror(depth_out); return 2; }
+            for (long i = 0; i < (long)width * height; ++i)
+                fwrite((double *)aa_depth_img.pixels + 4 * i, sizeof(double), 1, f);
+            fclose(f);
+            image_free(&aa_depth_img);
+        }
         long long rays_pass1 = n_trace_closest + n_trace_shadow;
         double *out = malloc(sizeof(double) * (size_t)width * height * 4);
         long long resampled = 0;

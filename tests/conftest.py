@@ -114,16 +114,22 @@ def golden(name):
 
 SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4d", "c5_hypercube4d",
                "c5_hypercube5d", "c5_hypercube6d", "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror",
-               "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d"]
+               "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "c5_hypercube9d", "c5_hypercube9d"]
 KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d", "c5_hypercube6d",
-             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d",
+             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "c5_hypercube9d",
              # 8192 queries each, half of them aimed at the items of every kd leaf: the global-memory tier
              "kat_hypercube6d", "kat_hypercube7d", "kat_hypercube8d"]
 # every BASELINE config at its stated size, 8-bit like the reference's PNG: configs[0] 256x256, [1] and [2] 1920x1080,
 # [3]'s 3840x2160 frame, [4]'s 6-D .. 8-D sweep at 1920x1080
 FULL_CASES = ["c1_hypercube3d_256", "c2_balls4d_1080p", "c3_random4d_1080p", "c4_random4d_4k", "c5_hypercube6d_1080p",
               "c5_hypercube7d_1080p", "c5_hypercube8d_1080p"]
-AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d", "aa_zoo4d_sbs", "aa_zoo4d_ou", "aa_vr_zoo4d"]
+AA_CASES = ["aa_c3_random4d", "aa_c1_hypercube3d", "aa_zoo4d", "aa_zoo4d_sbs", "aa_zoo4d_ou", "aa_vr_zoo4d",
+            # as an anaglyph (every sample is the mix of two eyes), and with the depth map render_image makes beside it
+            "aa_zoo3d_anaglyph", "aa_c3_random4d_depth"]
+# recursive anti-aliasing with a lens: every sample draws its lens point from drand48 (ndt.c:528) -- a stochastic render
+AA_LENS_CASES = ["aa_zoo4d_dof"]
 # stereo modes, VR / panorama cameras, depth maps (meta: "stereo"; data: "depth" when the case has a depth map)
 SAMPLED_CASES = ["ns_c3_random4d", "ns_zoo4d_dof", "al_zoo4d", "al_zoo3d_dof_n3", "ns_zoo4d_sbs", "ns_vr_zoo4d"]   # -n samples > 1 and / or area lights
+# ... as an anaglyph, frame-packed, and with a depth map (the LAST sample's hit)
+SAMPLED_MODE_CASES = ["ns_zoo3d_anaglyph", "ns_zoo3d_hidef", "ns_c3_random4d_depth"]
 VIEW_CASES = ["st_zoo4d_sbs", "st_zoo4d_ou", "st_zoo3d_anaglyph", "st_zoo3d_hidef", "vr_zoo4d", "pano_zoo5d_sbs", "depth_c3_random4d"]

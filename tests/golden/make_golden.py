@@ -127,6 +127,22 @@ CASES = {
                          share_scene="st_zoo4d_sbs"),
     "ns_vr_zoo4d": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, samples=4, v2=True, config="vr",
                         share_scene="vr_zoo4d"),
+    # ... as an anaglyph (two adaptive loops per pixel, left eye then right, ndt.c:636-647), frame-packed (the jitter spans
+    # 1/height of the 1080-line eye image, ndt.c:482-483 against :629), and with a depth map (the LAST sample's hit, ndt.c:362-373)
+    "ns_zoo3d_anaglyph": dict(scene="parity_zoo", dims=3, res=(32, 18), depth=6, fb=True, kat=0, samples=4, stereo=3, v2=True,
+                              depth_map=True, share_scene="st_zoo3d_anaglyph"),
+    "ns_zoo3d_hidef": dict(scene="parity_zoo", dims=3, res=(12, 2205), depth=4, fb=True, kat=0, samples=3, stereo=4, v2=True,
+                           share_scene="st_zoo3d_anaglyph"),
+    "ns_c3_random4d_depth": dict(scene="random", dims=4, res=(32, 18), depth=4, fb=True, kat=0, samples=4, v2=True, depth_map=True,
+                                 share_scene="depth_c3_random4d"),
+    # recursive anti-aliasing as an anaglyph (every sample is the mix of two eyes; the subdivision tests see the mix), with a
+    # depth map (the first pass's), and with a lens (every sample draws its lens point: a stochastic render, ndt.c:528)
+    "aa_zoo3d_anaglyph": dict(scene="parity_zoo", dims=3, res=(48, 36), depth=6, fb=True, kat=0, aa=(8, 2), stereo=3, v2=True,
+                              share_scene="st_zoo3d_anaglyph"),
+    "aa_c3_random4d_depth": dict(scene="random", dims=4, res=(64, 36), depth=4, fb=True, kat=0, aa=(20, 3), v2=True, depth_map=True,
+                                 share_scene="depth_c3_random4d"),
+    "aa_zoo4d_dof": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=6, fb=True, kat=0, aa=(8, 2), v2=True, config="dof",
+                         share_scene="ns_zoo4d_dof"),
     # area lights (LIGHT_DISK / LIGHT_RECT, ndt.c:116-147): a random point of the light per shading evaluation, so even
     # -n 1 is stochastic (the adaptive loop's repeats differ); the second case adds jitter and a lens
     "al_zoo4d": dict(scene="parity_zoo", dims=4, res=(32, 18), depth=5, fb=True, kat=0, samples=1, v2=True, config="area"),

@@ -11,7 +11,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import comparable, golden, GOLDEN, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
+from conftest import (comparable, golden, GOLDEN, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES,
+                      SAMPLED_MODE_CASES)
 
 pytestmark = pytest.mark.gpu
 
@@ -409,7 +410,12 @@ def test_recursive_antialiasing_vs_reference(gpu, name):
     g = golden(name)
     aa = (g.meta["aa_diff"], g.meta["aa_depth"])
     gpu.upload_scene(g.scene)
-    out, st = gpu.render(g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
+    if "depth" in g.data:
+        # the depth map render_image makes beside an anti-aliased image: the first pass's (ndt.c:930-935, 753-756)
+        out, dm, st = gpu.render(g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0), depth_map=True)
+        assert np.abs(dm - g.data["depth"]).max() < TOL_TIGHT and (dm > 0).any()
+    else:
+        out, st = gpu.render(g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
     ref = g.data["fb"]
     diff = np.abs(out - ref)
     # (the VR screen goes through sin / cos: ocml against glibc in the primary rays, as in the view cases)
@@ -579,6 +585,78 @@ def test_jittered_samples_statistically_match_the_oracle(gpu, oracle, name):
     assert np.array_equal(part, first[1::2])
 
 
+@pytest.mark.parametrize("name", SAMPLED_MODE_CASES)
+def test_jittered_samples_in_the_other_modes(gpu, oracle, name):
+    """-n > 1 as an anaglyph (two adaptive loops per pixel: left eye, then right), frame-packed (1080 + 45 + 1080 lines; the jitter
+    spans 1/height of the image, under half a line of an eye's), and with a depth map (every sample overwrites the pixel's depth,
+    the last one's stays: ndt.c:362-373).  The oracle reproduces the reference's fixtures bit for bit (test_oracle_golden.py);
+    the device is compared with an ensemble of oracle renders like the other sampled cases -- colours per value, and the depth
+    map against the spread of the ensemble's depth maps."""
+    g = golden(name)
+    gpu.upload_scene(g.scene)
+    stereo = g.meta.get("stereo", 0)
+    S, n_seeds, n_dev = 16, 16, 8
+    want_depth = "depth" in g.data
+    s0 = g.meta["seed48"]
+    ens, ens_d = [], []
+    for k in range(n_seeds):
+        r = oracle.render(g.scene, g.width, g.height, g.depth, samples=S, seed48=[(s0[0] + 7919 * k) & 0xffff, s0[1], s0[2]],
+                          stereo=stereo, depth_map=want_depth)
+        ens.append(r[0])
+        if want_depth:
+            ens_d.append(r[1])
+    ens = np.array(ens)
+    dev, dev_d = [], []
+    try:
+        for k in range(n_dev):
+            gpu.set_option("sample_seed", k)
+            r = gpu.render(g.width, g.height, g.depth, samples=S, stereo=stereo, depth_map=want_depth)
+            dev.append(r[0])
+            if want_depth:
+                dev_d.append(r[1])
+            assert r[-1].aa_samples >= S * (g.width * (g.height - (46 if stereo == 4 else 0))) * (2 if stereo == 3 else 1)
+    finally:
+        gpu.set_option("sample_seed", 0)
+    dev = np.array(dev)
+    # frame packing: the 45 blank lines + the line between them stay black with alpha 1 (the reference leaves their alpha unset)
+    if stereo == 4:
+        assert np.array_equal(dev[:, 1080:1126, :, :3], np.zeros_like(dev[:, 1080:1126, :, :3]))
+        ens, dev = np.array(ens, copy=True), np.array(dev, copy=True)
+        ens[:, 1080:1126, :, 3] = 0.0
+        dev[:, 1080:1126, :, 3] = 0.0
+    mu = ens.mean(axis=0)
+    se = np.sqrt(ens.var(axis=0, ddof=1) / n_seeds + dev.var(axis=0, ddof=1) / n_dev)
+    both = se > 1e-12
+    # values the sampling cannot move agree outright (but for the odd sliver pixel, as in the test above)
+    moved = np.abs(dev.mean(axis=0) - mu)[~both] >= 1e-9
+    assert moved.sum() <= 0.003 * moved.size + 1
+    t = np.clip((dev.mean(axis=0) - mu)[both] / se[both], -15, 15)
+    print("%s: %d noisy values, per-value t mean %+.3f (0 +- %.3f), rms %.2f" % (name, t.size, t.mean(), 1 / np.sqrt(t.size / 3.0),
+                                                                                 np.sqrt((t ** 2).mean())))
+    assert abs(t.mean()) < 4.5 / np.sqrt(t.size / 3.0) and np.sqrt((t ** 2).mean()) < 1.4
+    assert abs(dev[..., :3].mean() - ens[..., :3].mean()) < 0.003
+    if want_depth:
+        # a pixel's depth is ONE sample's (the last): where the oracle's draws all agree (the whole footprint sees one
+        # surface at one distance, or nothing) the device agrees; elsewhere it lies inside the range the footprint offers
+        ens_d, dev_d = np.array(ens_d), np.array(dev_d)
+        lo, hi = ens_d.min(axis=0), ens_d.max(axis=0)
+        flat = (hi - lo) < 1e-12
+        if flat.any():
+            # (but for the pixel an object covers a few per cent of: sixteen oracle draws whose last samples all missed it say
+            # "flat", and one of the device's last samples hits it)
+            off = np.abs(dev_d - ens_d[0])[:, flat] >= TOL_TIGHT
+            assert off.mean() < 0.02, off.mean()
+        slack = 0.25 * (hi - lo) + 1e-9
+        inside = (dev_d >= lo - slack) & (dev_d <= hi + slack)
+        assert inside.mean() > 0.97, inside.mean()
+        assert abs(dev_d.mean() - ens_d.mean()) < 0.05 * abs(ens_d.mean()) + 1e-6
+    # shards and repeats
+    a, b = gpu.render(g.width, g.height, g.depth, samples=4, stereo=stereo)[0], gpu.render(g.width, g.height, g.depth, samples=4, stereo=stereo)[0]
+    assert np.array_equal(a, b)
+    part = gpu.render(g.width, g.height, g.depth, samples=4, stereo=stereo, row_begin=1, row_step=2)[0]
+    assert np.array_equal(part, a[1::2])
+
+
 def test_area_lights_make_even_one_sample_stochastic(gpu, oracle):
     """LIGHT_DISK / LIGHT_RECT (ndt.c:116-147): a random point of the light per shading evaluation, so
     with -n 1 the adaptive loop's repeats differ and it keeps sampling until the running mean settles.
@@ -594,10 +672,57 @@ def test_area_lights_make_even_one_sample_stochastic(gpu, oracle):
     assert abs(out[..., :3].mean() - want[..., :3].mean()) < 0.01
     again, _ = gpu.render(g.width, g.height, g.depth, samples=1)
     assert np.array_equal(out, again)
-    # the modes that need the deterministic path say so
+    # under recursive anti-aliasing every sample is such a loop (the stochastic anti-aliased render, below)
+    aa_dev, sd = gpu.render(g.width, g.height, g.depth, aa=(20, 2))
+    aa_ora, so2 = oracle.render(g.scene, g.width, g.height, g.depth, aa=(20, 2), seed48=g.meta["seed48"])
+    assert np.abs(aa_dev[..., :3] - aa_ora[..., :3]).mean() < 0.03
+    assert abs(aa_dev[..., :3].mean() - aa_ora[..., :3].mean()) < 0.01
+    assert 0.5 * so2.pixels_resampled <= sd.pixels_resampled <= 1.5 * so2.pixels_resampled + 5
+    # ... and there is no depth map beside one
     from ndt_amd.hip import NdtHipError
     with pytest.raises(NdtHipError):
-        gpu.render(g.width, g.height, g.depth, aa=(20, 2))
+        gpu.render(g.width, g.height, g.depth, aa=(20, 2), depth_map=True)
+
+
+def test_recursive_antialiasing_with_a_lens(gpu, oracle):
+    """-a with aperture_radius != 0: the reference samples the lens in this mode too (ndt.c:528), so every anti-aliasing sample
+    is get_pixel_color's adaptive loop over lens samples and the subdivision runs on noisy colours.  The oracle reproduces the
+    reference's fixture bit for bit from the recorded drand48 state (test_oracle_golden.py); the device draws from its own
+    streams: an ensemble of device renders against an ensemble of oracle renders, per value and in the number of pixels
+    that were subdivided."""
+    g = golden("aa_zoo4d_dof")
+    aa = (g.meta["aa_diff"], g.meta["aa_depth"])
+    gpu.upload_scene(g.scene)
+    s0 = g.meta["seed48"]
+    n_ora, n_dev = 12, 8
+    ens, res_o = [], []
+    for k in range(n_ora):
+        img, so = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, seed48=[(s0[0] + 7919 * k) & 0xffff, s0[1], s0[2]])
+        ens.append(img)
+        res_o.append(so.pixels_resampled)
+    dev, res_d = [], []
+    try:
+        for k in range(n_dev):
+            gpu.set_option("sample_seed", k)
+            img, st = gpu.render(g.width, g.height, g.depth, aa=aa)
+            dev.append(img)
+            res_d.append(st.pixels_resampled)
+    finally:
+        gpu.set_option("sample_seed", 0)
+    ens, dev = np.array(ens), np.array(dev)
+    se = np.sqrt(ens.var(axis=0, ddof=1) / n_ora + dev.var(axis=0, ddof=1) / n_dev)
+    both = se > 1e-12
+    t = np.clip((dev.mean(axis=0) - ens.mean(axis=0))[both] / se[both], -15, 15)
+    print("aa_zoo4d_dof: %d noisy values, per-value t mean %+.3f (0 +- %.3f), rms %.2f; pixels resampled: device %s, oracle %s" % (
+        t.size, t.mean(), 1 / np.sqrt(t.size / 3.0), np.sqrt((t ** 2).mean()), sorted(res_d), sorted(res_o)))
+    assert abs(t.mean()) < 4.5 / np.sqrt(t.size / 3.0) and np.sqrt((t ** 2).mean()) < 1.4
+    assert abs(dev[..., :3].mean() - ens[..., :3].mean()) < 0.003
+    assert abs(np.mean(res_d) - np.mean(res_o)) < 4 * (np.std(res_o, ddof=1) / np.sqrt(n_ora) + np.std(res_d, ddof=1) / np.sqrt(n_dev)) + 2
+    again, _ = gpu.render(g.width, g.height, g.depth, aa=aa)
+    first, _ = gpu.render(g.width, g.height, g.depth, aa=aa)
+    assert np.array_equal(again, first)
+    part, _ = gpu.render(g.width, g.height, g.depth, aa=aa, row_begin=1, row_step=2)
+    assert np.array_equal(part, first[1::2])
 
 
 @pytest.mark.gpu

@@ -7,7 +7,8 @@ same glibc libm, no FMA, SSE lane-pair dot order.
 import numpy as np
 import pytest
 
-from conftest import comparable, golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES
+from conftest import (comparable, golden, SMALL_CASES, KAT_CASES, FULL_CASES, AA_CASES, VIEW_CASES, SAMPLED_CASES,
+                      SAMPLED_MODE_CASES, AA_LENS_CASES)
 
 
 @pytest.mark.parametrize("name", SMALL_CASES)
@@ -74,9 +75,27 @@ def test_recursive_antialiasing_bit_exact(oracle, name):
     reference's own render_line + resample_pixel, its "pixels resampled" count and its trace_kd count."""
     g = golden(name)
     aa = (g.meta["aa_diff"], g.meta["aa_depth"])
-    out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
+    if "depth" in g.data:
+        # the depth map render_image makes beside an anti-aliased image: the first pass's (ndt.c:930-935, 753-756)
+        out, dm, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0), depth_map=True)
+        assert np.array_equal(dm, g.data["depth"]) and (dm > 0).any()
+    else:
+        out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, stereo=g.meta.get("stereo", 0))
     ref = g.data["fb"]
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    assert st.pixels_resampled == g.meta["pixels_resampled"] > 0
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+@pytest.mark.parametrize("name", AA_LENS_CASES)
+def test_recursive_antialiasing_with_a_lens_bit_exact(oracle, name):
+    """-a with aperture_radius != 0: the reference samples the lens in this mode too (ndt.c:528: `recursive_aa != 0 ||
+    samples > 1`), one drand48 pair (or more: rejection) per get_pixel_color pass, and the adaptive loop runs until the
+    colour settles.  One thread, the stream started where the reference's stood: same numbers, same image, same counts."""
+    g = golden(name)
+    aa = (g.meta["aa_diff"], g.meta["aa_depth"])
+    out, st = oracle.render(g.scene, g.width, g.height, g.depth, aa=aa, seed48=g.meta["seed48"])
+    assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
     assert st.pixels_resampled == g.meta["pixels_resampled"] > 0
     assert st.rays_ref_equiv == g.meta["rays_total"]
 
@@ -120,4 +139,21 @@ def test_jittered_samples_and_lens_bit_exact(oracle, name):
     out, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"],
                             stereo=g.meta.get("stereo", 0))
     assert np.array_equal(out, g.data["fb"]), "max abs diff %g" % np.abs(out - g.data["fb"]).max()
+    assert st.rays_ref_equiv == g.meta["rays_total"]
+
+
+@pytest.mark.parametrize("name", SAMPLED_MODE_CASES)
+def test_jittered_samples_in_the_other_modes_bit_exact(oracle, name):
+    """-n > 1 as an anaglyph (two adaptive loops per pixel, left eye first), frame-packed, and with a depth map (every sample
+    overwrites the pixel's depth: the last one's stays, ndt.c:362-373)."""
+    g = golden(name)
+    stereo = g.meta.get("stereo", 0)
+    if "depth" in g.data:
+        out, dm, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"],
+                                    stereo=stereo, depth_map=True)
+        assert np.array_equal(dm, g.data["depth"]) and (dm > 0).any()
+    else:
+        out, st = oracle.render(g.scene, g.width, g.height, g.depth, samples=g.meta["samples"], seed48=g.meta["seed48"], stereo=stereo)
+    out, ref = comparable(out, stereo), comparable(g.data["fb"], stereo)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
     assert st.rays_ref_equiv == g.meta["rays_total"]
