@@ -403,6 +403,19 @@ def main():
             for _ in range(5):
                 gpu.render_rgba8(width, height, depth)
             line["ms_per_step_host_rgba8"] = (time.perf_counter() - t1) / 5 * 1e3
+            # ... and in a SEQUENCE of frames (an animation, the reference's real use): ndt_hip_render_rgba8_async -- the copy of
+            # frame k to pinned host memory runs behind the rendering of frame k + 1.  20 frames, the last one's arrival included.
+            pinned = [torch.empty((height, width, 4), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            gpu.render_rgba8_async(pinned[0].data_ptr(), width, height, depth)
+            gpu.render_rgba8_wait()
+            n_seq = 20
+            t1 = time.perf_counter()
+            for k in range(n_seq):
+                gpu.render_rgba8_async(pinned[k & 1].data_ptr(), width, height, depth)
+            gpu.render_rgba8_wait()
+            line["ms_per_step_host_rgba8_pipelined"] = (time.perf_counter() - t1) / n_seq * 1e3
+            check, _ = gpu.render_rgba8(width, height, depth)
+            line["host_rgba8_pipelined_bytes_identical"] = bool(np.array_equal(pinned[(n_seq - 1) & 1].numpy(), check))
         elif args.scaling == "strong" and not rehearsal:
             # the time this frame takes on ONE GPU (rank 0's, alone: the other ranks wait at the barrier below)
             whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")

@@ -256,6 +256,13 @@ enum ndt_image_format { NDT_IMAGE_F64 = 0, NDT_IMAGE_RGBA8 = 1 };
  * rows*width*4 bytes.  An eighth of ndt_hip_render's bytes cross PCIe. */
 int ndt_hip_render_rgba8(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats);
 
+/* The same without waiting for the bytes to arrive: the call returns when the frame is complete in HBM and quantised; its copy to
+ * `rgba8` -- pinned host memory -- runs on a copy stream behind the NEXT call's rendering.  `rgba8` must stay valid, and is not
+ * to be read, until ndt_hip_render_rgba8_wait returns (it waits for every frame begun on the context).  At most two copies are
+ * in flight.  What "rendering took" (ndt.c:978-984: pixels in host memory) costs per frame of a sequence is then the render. */
+int ndt_hip_render_rgba8_async(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats);
+int ndt_hip_render_rgba8_wait(ndt_hip_ctx *ctx);
+
 /* ONE frame over several contexts -- one per GPU of the node, or several on one GPU -- called from one host thread.
  * The rows `p` selects are dealt cyclically to the contexts exactly as the reference deals rows to MPI ranks in
  * MPI_MODE_ROW (ndt.c:812-820: row_start = rank, row_step = size): context k renders rows

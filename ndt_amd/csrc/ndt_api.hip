@@ -108,6 +108,7 @@ extern "C" int ndt_hip_destroy(ndt_hip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_workspace(ctx);
     free_stage(ctx);
+    free_async(ctx);
     if (ctx->d_shard) (void)hipFree(ctx->d_shard);
     if (ctx->d_image) (void)hipFree(ctx->d_image);
     for (auto &slot : ctx->pool)

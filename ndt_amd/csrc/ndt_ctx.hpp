@@ -98,6 +98,13 @@ struct ndt_hip_ctx {
     size_t d_shard_bytes = 0;
     void *d_image = nullptr;        // ndt_hip_render_multi (host output): the assembled frame on the first context's device
     size_t d_image_bytes = 0;
+    // ndt_hip_render_rgba8_async: two quantised frames in HBM, a copy stream, and per buffer the events "quantised" / "copied"
+    void *d_rgba8[2] = { nullptr, nullptr };
+    size_t d_rgba8_bytes[2] = { 0, 0 };
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_quantised[2] = { nullptr, nullptr }, ev_copied[2] = { nullptr, nullptr };
+    bool copy_pending[2] = { false, false };
+    int rgba8_turn = 0;
     // ndt_hip_render_multi without peer stores: this context's staging buffer and stream ON THE FIRST CONTEXT'S DEVICE
     void *d_stage = nullptr;
     size_t d_stage_bytes = 0;
@@ -143,6 +150,7 @@ void add_stats(ndt_render_stats &acc, const ndt_render_stats &st);
 // ndt_multi.hip
 void worker_stop(ndt_hip_ctx *ctx);
 void free_stage(ndt_hip_ctx *ctx);
+void free_async(ndt_hip_ctx *ctx);
 
 // ndt_aa.hip / ndt_sampled.hip
 int render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, ndt_render_stats &total, void *d_depth = nullptr);

@@ -21,7 +21,7 @@ API_SYMBOLS = [
     "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
     "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
-    "ndt_hip_item_boxes",
+    "ndt_hip_item_boxes", "ndt_hip_render_rgba8_async", "ndt_hip_render_rgba8_wait",
 ]
 
 IMAGE_F64, IMAGE_RGBA8 = 0, 1      # enum ndt_image_format
@@ -77,6 +77,8 @@ def load_library():
     lib.ndt_hip_device.argtypes = [C.c_void_p]
     lib.ndt_hip_multi_path_taken.argtypes = [C.c_void_p]
     lib.ndt_hip_item_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_rgba8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_render_rgba8_wait.argtypes = [C.c_void_p]
     lib.ndt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = lib
     return lib
@@ -217,6 +219,17 @@ class NdtHip:
         st = RenderStats()
         self._check(self.lib.ndt_hip_render_rgba8(self.ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
         return out, st
+
+    def render_rgba8_async(self, host_ptr, width, height, depth, **kw):
+        """ndt_hip_render_rgba8_async: the frame's bytes travel to pinned host memory at `host_ptr` behind the next call's
+        rendering; read them after render_rgba8_wait()."""
+        p = self.params(width, height, depth, **kw)
+        st = RenderStats()
+        self._check(self.lib.ndt_hip_render_rgba8_async(self.ctx, C.byref(p), C.c_void_p(host_ptr), C.byref(st)))
+        return st
+
+    def render_rgba8_wait(self):
+        self._check(self.lib.ndt_hip_render_rgba8_wait(self.ctx))
 
     def quantize_device(self, d_rgba_ptr, d_rgba8_ptr, n_pixels):
         self._check(self.lib.ndt_hip_quantize_device(self.ctx, C.c_void_p(d_rgba_ptr), C.c_void_p(d_rgba8_ptr),

@@ -388,6 +388,24 @@ def test_quantize_on_device(gpu, oracle):
     assert np.array_equal(q.cpu().numpy(), oracle.quantize(out))
 
 
+def test_frames_delivered_behind_the_next_render(gpu):
+    """ndt_hip_render_rgba8_async: the copy of a frame's bytes to pinned host memory runs behind the next frame's rendering; after
+    ndt_hip_render_rgba8_wait every frame of the sequence is the synchronous call's, byte for byte -- different sizes and scenes
+    in flight at once, more frames than buffers."""
+    import torch
+    g, g2 = golden("c3_random4d"), golden("zoo4d")
+    frames = [(g, 96, 54), (g, 128, 72), (g2, 64, 36), (g, 40, 22), (g2, 96, 54)]
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8).pin_memory() for _, w, h in frames]
+    for (gg, w, h), b in zip(frames, bufs):
+        gpu.upload_scene(gg.scene)
+        gpu.render_rgba8_async(b.data_ptr(), w, h, gg.depth)
+    gpu.render_rgba8_wait()
+    for (gg, w, h), b in zip(frames, bufs):
+        gpu.upload_scene(gg.scene)
+        want, _ = gpu.render_rgba8(w, h, gg.depth)
+        assert np.array_equal(b.numpy(), want)
+
+
 def test_bad_scene_is_rejected_not_rendered(gpu):
     from ndt_amd.hip import NdtHipError
     g = golden("c1_hypercube3d")
