@@ -942,6 +942,8 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     if (ctx->tier == 0 && sd.mask_words == 1) {
         if (item_sets) {
             for (int i = 0; i < fs->n_inf; ++i) sd.inf_bits |= 1ull << fs->inf_refs[i];
+            for (int i = 0; i < fs->n_items && i < 64; ++i)
+                    if (fs->objects[i].bounds_radius > 0) sd.gate_bits |= 1ull << i;
         } else {
             sd.mask_words = 2;          // the one-word kernels read sets: this scene takes the NDT_MASK_REG_WORDS-word ones
         }

@@ -85,6 +85,12 @@ struct ndt_hip_ctx {
     bool hull_box = true, face_box = true, shade_pair = true;
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
+    // item sets: the min_dist-free part of every gate before the walk (ndt_device.hpp:trace_kd).  0 never, 1 always, 2 (default)
+    // for passes of up to gate_prepass_below primaries -- measured (profiles/r03_gate_prepass.txt): 64x36 -6 %, 480x270 -4 %,
+    // 960x540 +2 %, 1080p -1 %, the 3-D scene at 1080p +2 %: it shortens the walk of a lone slow ray, and costs the busy chip
+    // about what it saves
+    int gate_prepass = 2;
+    long long gate_prepass_below = 400000;
     bool item_boxes = true;         // global-memory tier: orthotopes carry a box in one scene-wide frame (ndt_blob.hip:scene_item_boxes)
     int leaf_scan_group = 64;       // ... when at least this many lanes share the leaf
     bool leaf_scan = true;          // global-memory tier: lanes on the same leaf stage its items through LDS (ndt_device.hpp:cls_scan)

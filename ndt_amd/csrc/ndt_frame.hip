@@ -469,6 +469,9 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     }
 
     const NdtKernelTable *kt = ctx->kt;
+    // (the gate prepass of trace_kd: the scene description a pass's kernels get carries the gated items only when it is on)
+    SceneDesc sd_pass = ctx->sd;
+    if (ctx->gate_prepass == 0 || (ctx->gate_prepass == 2 && n_primary > ctx->gate_prepass_below)) sd_pass.gate_bits = 0ull;
     const long long stream_upto = ctx->stream_below;
     ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= stream_upto);
     const bool hybrid = !ctx->use_stream && ctx->pipeline == 3 && ctx->hybrid_level >= 1 && rg.max_depth > ctx->hybrid_level;
@@ -519,10 +522,10 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 hipExtLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ev_begin, nullptr, 0u, ws, sa, node_batches, sh_batches, 1);
             else
                 hipLaunchKernelGGL(k_stream_init, dim3(512), dim3(256), 0, s, ws, sa, node_batches, sh_batches, 1);
-            if (!sa.fused) kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
-            kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
+            if (!sa.fused) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
+            kt->frame_stream(s, ctx->d_blob, sd_pass, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
             if (!sa.fused)
-                hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+                hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
                                    rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
             if (prof)
                 hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
@@ -618,18 +621,18 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         int queue_slot = 0;
         int launches = 0;
-        kt->primary(s, ctx->d_blob, ctx->sd, ws, rg);
+        kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             const bool exit_probe = ctx->exit_probe;
             tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
-                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, a, b2);
+                kt->trace(s, ctx->d_blob, sd_pass, ws, tj, ctx->tier, ctx->sd.mask_words, a, b2);
                 trace_ev.push_back({ a, b2 });
                 trace_dbg.push_back(what);
             } else {
-                kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
+                kt->trace(s, ctx->d_blob, sd_pass, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
             }
             ++launches;
             return NDT_OK;
@@ -693,14 +696,14 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             // hit points, shadow rays of this bounce, and the rays of the next bounce -- in the same launch as the
             // lighting of the previous bounce, which is waiting for the shadow answers the last trace launch produced
             if (pending_finish >= 0 && fuse_shade) {
-                kt->shade_pair(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper, upper), rg, pending_finish, pending_upper, upper);
+                kt->shade_pair(s, ctx->d_blob, sd_pass, shade_ws(pending_upper, upper), rg, pending_finish, pending_upper, upper);
                 pending_finish = -1;
             } else {
                 if (pending_finish >= 0) {
-                    kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+                    kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper);
                     pending_finish = -1;
                 }
-                kt->shade_emit(s, ctx->d_blob, ctx->sd, shade_ws(0), rg, b, upper);
+                kt->shade_emit(s, ctx->d_blob, sd_pass, shade_ws(0), rg, b, upper);
             }
             hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
             long long next_upper = 2 * upper;           // each node spawns at most two
@@ -723,7 +726,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             pending_finish = b;
             pending_upper = upper;
         }
-        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, ctx->sd, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper);
         StreamArgs sa = ctx->sa;
         hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
         if (hybrid && n_run >= hand && hand < n_levels) {
@@ -757,7 +760,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                     ev_k0 = get_event(ctx, ev_n++);
                     ev_k1 = get_event(ctx, ev_n++);
                 }
-                kt->frame_stream(s, ctx->d_blob, ctx->sd, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
+                kt->frame_stream(s, ctx->d_blob, sd_pass, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
                 if (prof) {
                     trace_ev.push_back({ ev_k0, ev_k1 });
                     trace_dbg.push_back("frame kernel, bounces " + std::to_string(hand) + " ..");
@@ -772,10 +775,10 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             for (int b = n_run; b-- > 0;) {
                 long long blocks = (level_nodes[b] + 255) / 256;
                 if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
-                hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws, rg.specular, b);
+                hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, sd_pass, ws, rg.specular, b);
             }
         }
-        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, ctx->sd, ws,
+        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
                            rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
         const StreamCtl *sctl = streamed ? sa.ctl : nullptr;
         if (prof)
