@@ -334,11 +334,14 @@ __global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc s
 }
 
 // (the pixel itself: ndt_finish.hpp)
+// resolve0: the bottom-up combine of the primaries' own bounce (the last k_resolve) happens here, in the thread that then
+// finishes the pixel: one launch less at the end of a frame
 __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
-                                                       double *rgba, double *depth_out)
+                                                       double *rgba, double *depth_out, int resolve0)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long weighted = 0ull;
+    if (resolve0 && g < rg.n_primary) resolve_node(blob, sd, ws, rg.specular, g);
     if (g < rg.n_primary && ws.depth_left[g] > 0) weighted = finish_pixel<false>(blob, sd, ws, rg, N_, g, rgba, depth_out);
     // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
     // saturates near 90 atomics/us, and there are 32k wavefronts at 1080p)
@@ -526,7 +529,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             kt->frame_stream(s, ctx->d_blob, sd_pass, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
             if (!sa.fused)
                 hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
-                                   rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+                                   rg, ctx->dims, (double *)d_rgba, (double *)d_depth, 0);
             if (prof)
                 hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
             else
@@ -772,14 +775,14 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
-            for (int b = n_run; b-- > 0;) {
+            for (int b = n_run; b-- > 1;) {        // (bounce 0, the primaries: inside k_finish_pixels)
                 long long blocks = (level_nodes[b] + 255) / 256;
                 if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
                 hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, sd_pass, ws, rg.specular, b);
             }
         }
         hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
-                           rg, ctx->dims, (double *)d_rgba, (double *)d_depth);
+                           rg, ctx->dims, (double *)d_rgba, (double *)d_depth, n_run >= 1 ? 1 : 0);
         const StreamCtl *sctl = streamed ? sa.ctl : nullptr;
         if (prof)
             hipExtLaunchKernelGGL(k_frame_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, n_run, ctx->d_done, tag, sctl);

@@ -666,6 +666,9 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
     }
     VisitMask<MW> mask;
     init_visit_mask<MW>(mask, gblob, sd, ws);
+    // global-memory tier: the rays' projections on the item boxes' frame, one LDS slot per lane (ndt_device.hpp:item_box_meets)
+    double *box_slot = nullptr;
+    if (MW == 0 && !LDS && sd.off_obox > 0) box_slot = lds_blob + (size_t)(threadIdx.x >> 6) * (N * 128) + 2 * (threadIdx.x & 63);
     // Idle wavefronts: ONE per workgroup (the first: the watcher) looks at the frame's global words -- is everything done, are
     // there partial batches to close -- and tells the others through LDS.  With every idle wavefront doing that (a dozen
     // agent-scope loads of the same few words per round) a launch with more wavefronts than work spent its time in the queue
@@ -775,10 +778,10 @@ __global__ void __launch_bounds__(NDT_STREAM_MAX_BLOCK) k_frame_stream(const dou
                 {   // (diagnostic build: the phase stamps of the per-bounce trace kernel are not collected here)
                     unsigned long long ph[8] = {};
                     unsigned int cnt[8] = {}, occ[8] = {};
-                    trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack);
+                    trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, ph, cnt, occ, kstack, ClsLds{}, true, box_slot);
                 }
 #else
-                trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack);
+                trace_kd<N, MW, LSTACK>(blob, sd, mask, o, v, lim, obj, prim, kstack, ClsLds{}, true, box_slot);
 #endif
                 if (sa.wave_log) {
                     const unsigned int dt = (unsigned int)(wall_clock64() - pr_a);
@@ -943,9 +946,10 @@ static void launch_frame_stream(hipStream_t s, const double *blob, SceneDesc sd,
             NDT_LAUNCH_STREAM((k_frame_stream<NDT_MASK_REG_WORDS, true>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, lds);
         }
     } else {
-        int res = resident_blocks(k_frame_stream<0, false>, NDT_TRACE_BLOCK, 0);
+        const size_t lds = sd.off_obox > 0 ? (size_t)(NDT_TRACE_BLOCK / 64) * N * 128 * sizeof(double) : 0;      // the item boxes' ray slots
+        int res = resident_blocks(k_frame_stream<0, false>, NDT_TRACE_BLOCK, lds);
         const long long max_blocks = ws.mask_slab_lanes / NDT_TRACE_BLOCK;
         if (res > max_blocks) res = (int)max_blocks;
-        NDT_LAUNCH_STREAM((k_frame_stream<0, false>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, 0);
+        NDT_LAUNCH_STREAM((k_frame_stream<0, false>), grid_for_work(res, NDT_TRACE_BLOCK), NDT_TRACE_BLOCK, lds);
     }
 }
