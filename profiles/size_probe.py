@@ -12,7 +12,7 @@ depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 g = NdtHip(0)
 g.upload_scene(fs)
 buf = torch.empty((2160, 3840, 4), dtype=torch.float64, device="cuda")
-for w, h in ((64, 36), (240, 135), (480, 270), (960, 540), (1920, 1080), (2716, 1528), (3840, 2160)):
+for w, h in ((64, 36), (240, 135), (480, 270), (960, 540), (1152, 648), (1280, 720), (1408, 792), (1920, 1080), (2716, 1528), (3840, 2160)):
     for _ in range(3):
         g.render_device(buf.data_ptr(), w, h, depth)
     torch.cuda.synchronize()
