@@ -146,8 +146,8 @@ typedef struct ndt_flat_scene {
 
     /* ABI 2 -- the rest of the camera (camera.h:34-76), used by recursive anti-aliasing, stereo
      * modes and the VR / panorama cameras; offsets into vecs, -1 when the producer has none.
-     * cam_aperture_radius != 0 makes recursive AA and samples>1 draw from the reference's global
-     * drand48 stream (ndt.c:528-542): such frames are rejected, parity would only be statistical. */
+     * cam_aperture_radius != 0 makes recursive AA and samples>1 sample the lens (ndt.c:528-542: the reference's global
+     * drand48 stream; here counter-based streams): such frames are stochastic renders, parity is statistical. */
     double  cam_aperture_radius;
     double  cam_h_fov, cam_v_fov;                            /* camera.h:52-53 */
     int32_t cam_left_eye_off, cam_right_eye_off;             /* camera.h:60-61 */
@@ -165,7 +165,8 @@ typedef struct ndt_render_params {
     int32_t samples;            /* `-n`.  1 = the deterministic path.  > 1 = jittered samples + lens
                                  * sampling + the adaptive loop (ndt.c:470-568) with a per-(pixel, sample) counter-based
                                  * random stream: reproducible, independent of sharding, statistically equivalent to
-                                 * the reference's drand48 stream (mono planar camera, no recursive_aa, no depth map) */
+                                 * the reference's drand48 stream; in every stereo mode, through every camera, with or
+                                 * without a depth map (a pixel's depth is then its LAST sample's, ndt.c:362-373) */
     int32_t row_begin, row_step;
     int32_t specular;           /* 1 = specular_enabled (ndt.c:41) */
     int32_t profile;            /* 1 = bracket trace kernels with hipEvents (fills *_ms below) */
@@ -177,7 +178,7 @@ typedef struct ndt_render_params {
     int32_t recursive_aa;       /* 0 = off */
     int32_t aa_diff;            /* reference default 20 (ndt.c:1412) */
     int32_t aa_depth;           /* reference default 4 (ndt.c:1411) */
-    int32_t stereo;             /* ndt_stereo_mode (needs the eyes in the flat scene); with recursive_aa: mono, side-by-side, over/under */
+    int32_t stereo;             /* ndt_stereo_mode (needs the eyes in the flat scene); with recursive_aa: every mode but HIDEF */
     int32_t reserved[4];        /* must be 0 */
 } ndt_render_params;
 
@@ -231,7 +232,8 @@ int ndt_hip_render(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, n
 
 /* The same with the depth map render_image fills when it is given a depth file name (ndt.c:930-935,
  * 753-756): `depth` receives rows*width doubles, 1/distance of the primary hit (the left eye's for
- * ANAGLYPH), 0 where the primary ray misses.  Not with recursive_aa.  (The reference leaves the
+ * ANAGLYPH), 0 where the primary ray misses.  With recursive_aa: the first pass's depths (ndt.c:930-935) -- but not beside
+ * a stochastic anti-aliased render (a lens, area lights or samples > 1 under recursive_aa).  (The reference leaves the
  * previous pixel's value when the hit lies within EPSILON of the eye; this library writes 0.) */
 int ndt_hip_render_depth_device(ndt_hip_ctx *ctx, const ndt_render_params *p, void *d_rgba, void *d_depth, ndt_render_stats *stats);
 int ndt_hip_render_depth(ndt_hip_ctx *ctx, const ndt_render_params *p, double *rgba, double *depth, ndt_render_stats *stats);

@@ -121,7 +121,7 @@ static double bearing_in_plane(const vectNd *from, const vectNd *to, int i, int 
 #define RIG_POINTS 5
 static void rig_turn(vectNd *const rig[RIG_POINTS], const vectNd *about, int i, int j, double angle)
 {
-    for (int k = 0; k < RIG_POINTS; ++k) vectNd_rotate(rig[k], about, i, j, angle, rig[k]);
+    for (int k = 0; k < RIG_POINTS; ++k) vectNd_rotate(rig[k], (vectNd *)about, i, j, angle, rig[k]);
 }
 
 int camera_aim_naive(camera *cam)
