@@ -956,6 +956,23 @@ template <int MW> struct VisitMask {
 };
 
 
+#ifdef NDT_PHASE_TIMING
+// diagnostic build only: wave-level cycle stamps per phase (never enabled in the shipped library)
+#define NDT_STAMP(slot)                                                   \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();     \
+        ph[slot] += now_ - ph_last;                                       \
+        ph_last = now_;                                                   \
+    } while (0)
+#define NDT_COUNT(slot) (cnt[slot] += 1)
+/* wave-level occupancy of a loop body: iterations and active lanes (same value in every active lane) */
+#define NDT_OCC(slot) do { occ[2 * (slot)] += 1; occ[2 * (slot) + 1] += __popcll(__ballot(1)); } while (0)
+#else
+#define NDT_STAMP(slot) do { } while (0)
+#define NDT_COUNT(slot) do { } while (0)
+#define NDT_OCC(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ coherent leaf scan (global-memory tier)
 //
 // In the 6-D .. 8-D scenes a leaf holds 60 .. 227 items and the 64 rays of a wavefront -- an 8x8 pixel tile, or 64 shadow
@@ -998,7 +1015,11 @@ NDT_DEV void cls_lds_sync()
 template <int N, int MW>
 NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<MW> &mask, double *win, const bool mine,
                       const double (&o)[N], const double (&v)[N], const double dist_limit, const int w0, const int e0,
-                      double *box_slot, bool &boxed, double &min_dist, int &best, int &last)
+                      double *box_slot, bool &boxed, double &min_dist, int &best, int &last
+#ifdef NDT_PHASE_TIMING
+                      , unsigned long long (&ph)[8], unsigned long long &ph_last
+#endif
+                      )
 {
     const int lane = __lane_id();
     double *l_ref = win, *l_inf = win + 64, *l_ord = win + 128, *l_win = win + 192, *l_par = win + 192 + 64 * 2 * N;
@@ -1049,6 +1070,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
             for (int c = 0; c < N; ++c) *reinterpret_cast<ndt_v2d *>(l_win + lane * 2 * N + 2 * c) = w2[c];
         }
         cls_lds_sync();
+        NDT_STAMP(4);
         // ---- which of them this ray has visited already (rays past their first leaf)
         unsigned long long seen = 0ull;
         if (open && mask.hist_n > 0) {
@@ -1079,6 +1101,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
             }
             want &= ~seen;
         }
+        NDT_STAMP(7);
         // ---- items, in list order; the record of the next one travels while this one is intersected
         int cur = 0;
         auto record_of = [&](int k, int &flags, int &words, int &m, int &at, int &sph) {
@@ -1147,6 +1170,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
             if (__ballot(open) == 0ull) any = 0ull;
         }
         cls_lds_sync();
+        NDT_STAMP(2);
         // a lane that is still scanning has looked at every item of the window
         if (open) last = (int)(__double_as_longlong(l_ref[cnt - 1]) & 0xffffffffll);
         cls_lds_sync();
@@ -1178,22 +1202,6 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
 // pointer is a plain local so that it stays in a register (as a member of a struct holding the
 // arrays it lived in scratch too, and every push / pop paid two extra dependent round trips).
 
-#ifdef NDT_PHASE_TIMING
-// diagnostic build only: wave-level cycle stamps per phase (never enabled in the shipped library)
-#define NDT_STAMP(slot)                                                   \
-    do {                                                                  \
-        const unsigned long long now_ = __builtin_readcyclecounter();     \
-        ph[slot] += now_ - ph_last;                                       \
-        ph_last = now_;                                                   \
-    } while (0)
-#define NDT_COUNT(slot) (cnt[slot] += 1)
-/* wave-level occupancy of a loop body: iterations and active lanes (same value in every active lane) */
-#define NDT_OCC(slot) do { occ[2 * (slot)] += 1; occ[2 * (slot) + 1] += __popcll(__ballot(1)); } while (0)
-#else
-#define NDT_STAMP(slot) do { } while (0)
-#define NDT_COUNT(slot) do { } while (0)
-#define NDT_OCC(slot) do { } while (0)
-#endif
 
 // Where the traversal stack lives.  Scratch (per-lane arrays in private memory) always works; LDS
 // (one slot per lane and level, [level][lane] so that lanes never share a bank) takes the push /
@@ -1494,7 +1502,12 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 if (__ballot(mine) == 0ull) continue;
                 double md;
                 int best, last;
+                NDT_STAMP(3);
+#ifdef NDT_PHASE_TIMING
+                cls_scan<N, MW>(blob, sd, mask, cl.base, mine, o, v, dist_limit, w0, e0, box_slot, boxed, md, best, last, ph, ph_last);
+#else
                 cls_scan<N, MW>(blob, sd, mask, cl.base, mine, o, v, dist_limit, w0, e0, box_slot, boxed, md, best, last);
+#endif
                 if (mine) {
                     min_dist = md;
                     best_obj = best;

@@ -948,6 +948,8 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 if (d[4]) {
                     // NDT_PHASE_TIMING builds only (make -C ndt_amd/csrc timing)
                     fprintf(stderr, "ndt_hip: wave cycles T %llu G %llu I %llu list-end %llu prologue %llu outside %llu over %llu waves\n", d[0], d[1], d[2], d[3], d[5], d[6], d[4]);
+                    if (d[7] || d[32])
+                        fprintf(stderr, "ndt_hip:    coherent leaf scan: fetching windows %llu, boxes / gates of the windows %llu (its intersections are in I)\n", d[32], d[7]);
                     fprintf(stderr, "ndt_hip: per-ray counts over %llu rays: node visits %llu, face gates %llu (pass %llu), item gates %llu (pass %llu), isect hits %llu\n",
                             d[14], d[8], d[9], d[10], d[11], d[12], d[13]);
                     fprintf(stderr, "ndt_hip: batch time inside trace_kd (100 MHz wall clock): closest max %.1f us mean %.1f us, shadow max %.1f us mean %.1f us\n",

@@ -555,6 +555,8 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         }
         if (lane == 0) {
             for (int i = 0; i < 4; ++i) atomicAdd(&ws.dbg[i], ph[i]);
+            atomicAdd(&ws.dbg[7], ph[7]);           // coherent leaf scan: gates / boxes of a window
+            atomicAdd(&ws.dbg[32], ph[4]);          // ... fetching a window
             atomicAdd(&ws.dbg[4], 1ull);
             atomicAdd(&ws.dbg[5], ph[5]);
             atomicAdd(&ws.dbg[6], ph[6]);
