@@ -11,8 +11,14 @@
 //   k_shade_finish second half of apply_lights (ndt.c:217-310) + the reflect / refract spawn
 //                  of get_ray_color (ndt.c:381-430)                           -> next bounce
 #if NDT_DIMS <= 5 && !defined(NDT_OUTLINE_SMALL)
-// inlined libm and hit-point intersection for the small vectors, out of line for 6-D .. 8-D (ndt_device.hpp, NDT_LIBM)
+// inlined libm for the small vectors, out of line from 6-D on (ndt_device.hpp, NDT_LIBM)
 #define NDT_INLINE_LIBM 1
+#endif
+#if NDT_DIMS <= 7 && !defined(NDT_OUTLINE_SMALL)
+// The hit-point intersection of the lighting kernels inlined up to 7-D, a real function from 8-D on.  (Round 3: the call hands
+// 4N doubles in and 2N out, and past 32 argument registers they travel through the stack -- 352 bytes of scratch a lane at
+// 6-D, real memory traffic; inlined, 1080p: 6-D 1.41 -> 1.35 ms, 7-D 2.02 -> 1.97, 8-D 3.26 -> 3.28.  shade_emit, which needs
+// few registers of its own, always has it inline: 6-D 1.59 -> 1.41 ms, 8-D 3.47 -> 3.26, 127 registers instead of 180 + scratch.)
 #define NDT_SHADE_INLINE_ISECT 1
 #endif
 #include "ndt_kernels.hpp"
@@ -687,8 +693,10 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
 struct VecPair {
     double a[N], b[N];
 };
-#ifndef NDT_SHADE_INLINE_ISECT
-// (arguments and results by value: they travel in registers; by pointer the caller's vectors would live in private memory)
+// (arguments and results by value: they travel in registers as far as 32 of them go, then through the stack; by pointer the
+// caller's vectors would live in private memory altogether)
+#if NDT_DIMS >= 6 && !defined(NDT_STREAM_INLINE_ISECT)
+#define NDT_HAVE_ISECT_CALL 1
 __device__ __attribute__((noinline)) VecPair isect_full_call(const double *blob, const SceneDesc *sd, int prim, VecPair ray)
 {
     VecPair out;
@@ -697,8 +705,8 @@ __device__ __attribute__((noinline)) VecPair isect_full_call(const double *blob,
     isect<N, true>(blob, *sd, prim, ray.a, ray.b, out.a, out.b);
     return out;
 }
-NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
-                        double (&nrm)[N])
+NDT_DEV void isect_full_outlined(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N],
+                                 double (&hit)[N], double (&nrm)[N])
 {
     VecPair ray;
 #pragma unroll
@@ -707,13 +715,27 @@ NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const
 #pragma unroll
     for (int c = 0; c < N; ++c) { hit[c] = out.a[c]; nrm[c] = out.b[c]; }
 }
-#else
+#endif
+// the lighting kernels of the per-bounce pipeline: inline up to 7-D (NDT_SHADE_INLINE_ISECT, top of this file)
 NDT_DEV void isect_full(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N], double (&hit)[N],
                         double (&nrm)[N])
 {
+#if defined(NDT_SHADE_INLINE_ISECT) || !defined(NDT_HAVE_ISECT_CALL)
     isect<N, true>(blob, *sd, prim, o, v, hit, nrm);
-}
+#else
+    isect_full_outlined(blob, sd, prim, o, v, hit, nrm);
 #endif
+}
+// the frame kernel (ndt_stream.hpp): a real function from 6-D on (156 -> 65 KB of code, fewer spills: round 2's measurement)
+NDT_DEV void isect_full_stream(const double *blob, const SceneDesc *sd, int prim, const double (&o)[N], const double (&v)[N],
+                               double (&hit)[N], double (&nrm)[N])
+{
+#ifdef NDT_HAVE_ISECT_CALL
+    isect_full_outlined(blob, sd, prim, o, v, hit, nrm);
+#else
+    isect<N, true>(blob, *sd, prim, o, v, hit, nrm);
+#endif
+}
 
 
 
@@ -839,7 +861,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             load_soa<N>(ws.ray_v, ws.cap, g, look);
             // the hit point and normal trace_kd would have returned: re-run the one primitive
             // that won the traversal (same arithmetic, same result)
-            isect_full(blob, &sd, ws.hit_prim[g], src, look, hit, nrm);
+            isect<N, true>(blob, sd, ws.hit_prim[g], src, look, hit, nrm);      // (always inline here: see NDT_SHADE_INLINE_ISECT)
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && level == 0) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;    // ndt.c:366-370

@@ -298,7 +298,7 @@ NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const Sce
             } else {
                 if (sobj != obj) continue;                  // ndt.c:217
                 double light_hit[N];
-                isect_full(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                isect_full_stream(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
                 const double dist = v_dist<N>(hit, light_hit);
                 if (dist > NDT_EPS) continue;               // ndt.c:225
             }
@@ -361,7 +361,7 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
     if (valid) {
         if (obj >= 0) {
             // the hit point and normal trace_kd would have returned: re-run the one primitive that won the traversal
-            isect_full(blob, &sd, prim, src, look, hit, nrm);
+            isect_full_stream(blob, &sd, prim, src, look, hit, nrm);
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && sa.roots_are_primaries && g < sa.n_primary) cst(ws.depth + g, shaded ? 1.0 / trace_dist : 0.0);     // ndt.c:366-370
