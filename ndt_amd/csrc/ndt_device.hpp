@@ -1230,7 +1230,11 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     // v_inv of kd_tree_intersect (kd-tree.c:576-590), clamped to +-1/EPS^2.  The LDS tiers keep all N in registers (a tree
     // step reads one per node).  The global-memory tier -- a ray walks one root-to-leaf path and then scans hundreds of
     // items -- computes the one it needs at each node instead: N registers (16 in 8-D) the list scan can use.
+#ifdef NDT_T1_KEEP_INV
+    constexpr bool KEEP_INV = true;         // (experiment: all N in registers in the global-memory tier too)
+#else
     constexpr bool KEEP_INV = (MW != 0);
+#endif
     auto inv_of = [](double v_i) {
         double r;
         if (v_i < NDT_EPS2 && v_i >= 0.0)

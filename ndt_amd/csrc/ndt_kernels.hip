@@ -865,10 +865,9 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && level == 0) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;    // ndt.c:366-370
-            if (shaded) {
-                store_soa<N>(ws.hit_p, ws.cap, g, hit);
-                store_soa<N>(ws.hit_n, ws.cap, g, nrm);
-            } else {
+            // (hit point and normal are not stored: shade_finish makes them again from the winning primitive, like every other
+            // consumer of a trace result -- 4N doubles less written and read per node; balls 0.967 -> 0.943 ms, the others +-0)
+            if (!shaded) {
                 ws.hit_obj[g] = -1;
             }
         }
@@ -1097,8 +1096,8 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
         double src[N], look[N], nrm[N], hit[N];
         load_soa<N>(ws.ray_o, ws.cap, g, src);
         load_soa<N>(ws.ray_v, ws.cap, g, look);
-        load_soa<N>(ws.hit_p, ws.cap, g, hit);
-        load_soa<N>(ws.hit_n, ws.cap, g, nrm);
+        // the hit point and normal trace_kd would have returned, as in shade_emit: same function, same operands, same bits
+        isect_full(blob, &sd, ws.hit_prim[g], src, look, hit, nrm);
         const int mw = sd.off_mat + 8 * obj;
         const double hit_r = blob[mw], hit_g = blob[mw + 1], hit_b = blob[mw + 2];
         const double refl_r = blob[mw + 3], refl_g = blob[mw + 4], refl_b = blob[mw + 5];

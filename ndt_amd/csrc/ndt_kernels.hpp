@@ -26,7 +26,7 @@ struct Workspace {
     double *frac;               // [cap]      pixel_frac (ndt.c:330)
     int *depth_left;            // [cap]      max_depth of this node; 0 = padding slot
     int *hit_obj, *hit_prim;    // [cap]      trace_kd result: material owner / primitive; <0 = miss
-    double *hit_p, *hit_n;      // [N][cap]   hit point / normal (apply_lights inputs)
+    double *hit_p, *hit_n;      // [N][cap]   hit point / normal: the trace_rays API's answers only (the shade kernels recompute them)
     double *clr;                // [3][cap]   local colour, then resolved colour
     int *child_refl, *child_refr; // [cap]    -1 none, -2 cut-off (black), >=0 node
     int *sh_idx;                // [n_seg][cap] index of this node's shadow ray inside its light's segment
