@@ -259,9 +259,10 @@ enum ndt_image_format { NDT_IMAGE_F64 = 0, NDT_IMAGE_RGBA8 = 1 };
 int ndt_hip_render_rgba8(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats);
 
 /* The same without waiting for the bytes to arrive: the call returns when the frame is complete in HBM and quantised; its copy to
- * `rgba8` -- pinned host memory -- runs on a copy stream behind the NEXT call's rendering.  `rgba8` must stay valid, and is not
- * to be read, until ndt_hip_render_rgba8_wait returns (it waits for every frame begun on the context).  At most two copies are
- * in flight.  What "rendering took" (ndt.c:978-984: pixels in host memory) costs per frame of a sequence is then the render. */
+ * `rgba8` -- pinned host memory -- runs on a copy stream behind the NEXT call's rendering.  When a call returns, every EARLIER
+ * frame of the context has arrived in its buffer; the frame of the call itself has when the next call, or
+ * ndt_hip_render_rgba8_wait, returns -- until then `rgba8` must stay valid and is not to be read.  What "rendering took"
+ * (ndt.c:978-984: pixels in host memory) costs per frame of a sequence is then the render. */
 int ndt_hip_render_rgba8_async(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats);
 int ndt_hip_render_rgba8_wait(ndt_hip_ctx *ctx);
 

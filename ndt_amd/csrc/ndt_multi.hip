@@ -81,9 +81,10 @@ extern "C" int ndt_hip_render_rgba8(ndt_hip_ctx *ctx, const ndt_render_params *p
 // alone (the reference's "rendering took" ends with the pixels in host memory, ndt.c:978-984: ndt_hip_render_rgba8 -- render,
 // then 8 MB over PCIe, in sequence -- is 1.80 ms where the render is 1.46).
 //   ndt_hip_render_rgba8_async(ctx, p, rgba8, stats)   rgba8: host memory, pinned (hipHostMalloc / torch pin_memory) for the copy
-//                                                      to be asynchronous; it must stay valid, and is not to be read, until
-//   ndt_hip_render_rgba8_wait(ctx)                     ... returns: every frame begun on this context has arrived.
-// At most two copies are in flight: the third call first waits for the first one's.
+//                                                      to be asynchronous.  When the call returns, THIS frame is rendered and on
+//                                                      its way, and every EARLIER frame of the context has arrived (its copy had
+//                                                      the whole of this frame's rendering to finish: the wait is free);
+//   ndt_hip_render_rgba8_wait(ctx)                     ... the last one too.
 extern "C" int ndt_hip_render_rgba8_async(ndt_hip_ctx *ctx, const ndt_render_params *p, uint8_t *rgba8, ndt_render_stats *stats)
 {
     if (!ctx || !p || !rgba8) return fail(NDT_E_INVALID, "NULL argument");
@@ -118,6 +119,10 @@ extern "C" int ndt_hip_render_rgba8_async(ndt_hip_ctx *ctx, const ndt_render_par
     HIP_TRY(hipMemcpyAsync(rgba8, ctx->d_rgba8[k], pixels * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
     HIP_TRY(hipEventRecord(ctx->ev_copied[k], ctx->copy_stream));
     ctx->copy_pending[k] = true;
+    if (ctx->copy_pending[k ^ 1]) {         // the frame before: it travelled while this one was rendered
+        HIP_TRY(hipEventSynchronize(ctx->ev_copied[k ^ 1]));
+        ctx->copy_pending[k ^ 1] = false;
+    }
     return NDT_OK;
 }
 

@@ -396,9 +396,15 @@ def test_frames_delivered_behind_the_next_render(gpu):
     g, g2 = golden("c3_random4d"), golden("zoo4d")
     frames = [(g, 96, 54), (g, 128, 72), (g2, 64, 36), (g, 40, 22), (g2, 96, 54)]
     bufs = [torch.zeros((h, w, 4), dtype=torch.uint8).pin_memory() for _, w, h in frames]
-    for (gg, w, h), b in zip(frames, bufs):
+    sync = {}
+    for k, (gg, w, h) in enumerate(frames):
+        gpu.upload_scene(gg.scene)
+        sync[k] = gpu.render_rgba8(w, h, gg.depth)[0]
+    for k, ((gg, w, h), b) in enumerate(zip(frames, bufs)):
         gpu.upload_scene(gg.scene)
         gpu.render_rgba8_async(b.data_ptr(), w, h, gg.depth)
+        if k > 0:       # when the call returns, the frame before has arrived
+            assert np.array_equal(bufs[k - 1].numpy(), sync[k - 1]), k
     gpu.render_rgba8_wait()
     for (gg, w, h), b in zip(frames, bufs):
         gpu.upload_scene(gg.scene)
