@@ -8,7 +8,10 @@ export TMPDIR=/tmp
 cd /root/repo 2>/dev/null || true
 O=gpurun_out/r03_final
 mkdir -p $O
-trap "cp profiles/r03_* $O/ 2>/dev/null" EXIT
+# only what THIS call wrote goes back (the other part's files in the snapshot may be older than what that part last produced)
+touch $O/.start
+give_back() { find profiles -maxdepth 1 -name 'r03_*' -newer $O/.start -exec cp {} $O/ \; 2>/dev/null; }
+trap give_back EXIT
 # in two calls (gpurun's limit is 20 minutes): PART=1 the GPU tests + the three 3-D / 4-D workloads, PART=2 the 6-D .. 8-D sweep + the probes
 PART=${PART:-1}
 if [ "$PART" = 1 ]; then
@@ -17,7 +20,7 @@ grep "bytes differ\|noisy values\|per-value t\|reference-equivalent rays" $O/tes
 for w in random4d balls4d hypercube3d; do
   bash profiles/profile_workload.sh $w || exit 1
 done
-cp profiles/r03_* $O/ 2>/dev/null
+give_back
 exit 0
 fi
 for w in hypercube6d hypercube7d hypercube8d; do
@@ -36,5 +39,5 @@ timeout -k 10 200 python profiles/size_probe.py 2>&1 | grep -v amdgpu > profiles
 timeout -k 10 300 python profiles/shard_probe.py 1 2 4 8 2>&1 | grep -v amdgpu > profiles/r03_shard_probe_strong.txt; cat profiles/r03_shard_probe_strong.txt
 NDT_HIP_PIPELINE=levels timeout -k 10 200 python profiles/shard_probe.py 8 2>&1 | grep -v amdgpu > profiles/r03_shard_probe_strong_levels_n8.txt
 NDT_HIP_STREAM_PROBE=1 timeout -k 10 100 python profiles/stream_probe.py random4d 64x36 960x540 2>&1 | grep -v amdgpu > profiles/r03_stream_probe_random4d.txt
-cp profiles/r03_* $O/ 2>/dev/null
+give_back
 tail -1 profiles/r03_bench_default.json.log | cut -c1-400
