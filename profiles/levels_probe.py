@@ -13,6 +13,7 @@ ap.add_argument("--scene", default="c3_random4d")
 ap.add_argument("--res", default="1920x1080")
 ap.add_argument("--depth", type=int, default=4)
 ap.add_argument("--drop-type", default="")
+ap.add_argument("--opt", action="append", default=[], help="name=value for ndt_hip_set_option, before the scene is uploaded")
 a = ap.parse_args()
 fs = load_scene("tests/golden/%s.ndtscene.gz" % a.scene)
 if a.drop_type:
@@ -31,6 +32,8 @@ if a.drop_type:
 w, h = (int(x) for x in a.res.split("x"))
 g = NdtHip(0)
 g.set_option("pipeline", 1)             # the per-bounce kernels: what the phase stamps instrument
+for kv in a.opt:
+    g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 g.upload_scene(fs)
 for i in range(3):
     g.render(w, h, a.depth)
