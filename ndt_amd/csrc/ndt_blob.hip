@@ -375,7 +375,19 @@ bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o
         }
     }
     if (best < 0) return false;
-    rows = best_rows;
+    // thinnest slab first: the device asks after every slab whether any ray of the wavefront is still inside
+    // (ndt_device.hpp:hull_faces), and two thin slabs reject what four in any order would
+    {
+        std::vector<int> order((size_t)n);
+        for (int a = 0; a < n; ++a) order[(size_t)a] = a;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return best_rows[(size_t)x * (n + 2) + n + 1] < best_rows[(size_t)y * (n + 2) + n + 1];
+        });
+        rows.clear();
+        for (int a = 0; a < n; ++a)
+            rows.insert(rows.end(), best_rows.begin() + (size_t)order[(size_t)a] * (n + 2),
+                        best_rows.begin() + (size_t)(order[(size_t)a] + 1) * (n + 2));
+    }
     if (faces) {
         // Every face's own box in the chosen frame.  The hull box is the union of these: a ray that misses box f
         // cannot produce a point face f's intersect() accepts (same argument, one face at a time), so the device

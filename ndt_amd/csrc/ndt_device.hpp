@@ -689,32 +689,60 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
 // at most 63 of them).  The projections u_k.o and 1/(u_k.v) of the hull test are shared by all the faces, so a
 // face costs N slab updates -- against ~20 orthotope intersections per hcube visit on the benchmark scene, of which
 // almost all missed.
+// Cost, as measured on the benchmark frame (profiles/r03_hull_probe.txt): 41 % of its rays pass the bounding-sphere gate of an
+// hcube somewhere, 1 % meet a hull box, 0.002 % a face box -- and because ONE lane in this code keeps its wavefront waiting, almost
+// every scan step of every wavefront paid for the hull test of two or three lanes.  Hence:
+//   * the slabs come thinnest first (ndt_blob.hip sorts them) and after every slab from the second on the wavefront asks whether
+//     any of its rays is still inside: two thin slabs usually settle it;
+//   * 1/(u_k.v) is the hardware's reciprocal with one Newton step, not an IEEE division (a third of the old test's instructions
+//     were its N divisions): the test is a filter, not part of the reference's arithmetic, and it stays conservative because every
+//     comparison of interval ends gives way by 2^-30 of their size (NDT_SLAB_GIVE) -- a million times the reciprocal's error;
+//   * the face boxes give up the same way, two slabs at a time.
+#define NDT_SLAB_GIVE 9.313225746154785e-10         /* 2^-30 */
+NDT_DEV double slab_rcp(double d)
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+// false only when the interval [lo, hi] is empty by more than the reciprocal's error can account for (NaN: not empty)
+NDT_DEV bool slab_interval_holds(double lo, double hi)
+{
+    return !(__builtin_fma(-fabs(lo), NDT_SLAB_GIVE, lo) > __builtin_fma(fabs(hi), NDT_SLAB_GIVE, hi));
+}
 template <int N>
 NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N])
 {
     double po[N], inv[N];       // u_k.o and 1/(u_k.v); 0 marks a ray parallel to slab k
     double t0 = 0.0, t1 = NDT_DBL_MAX;
     bool ok = true;
+    bool any = true;            // wave-uniform: some ray of the wavefront is still inside the slabs so far
+    // (no early exit from the loops: they would not unroll, and po / inv would be indexed in scratch)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double u[N];
-        blob_vec<N>(blob, p + k * (N + 2), u);
-        po[k] = v_dot<N>(u, o);
-        const double a = po[k] - blob[p + k * (N + 2) + N];
-        const double d = v_dot<N>(u, v);
-        const double h = blob[p + k * (N + 2) + N + 1];
-        if (fabs(d) < 1e-200) {
-            inv[k] = 0.0;
-            if (fabs(a) > h) ok = false;        // parallel to the slab and outside it
-        } else {
-            inv[k] = 1.0 / d;
-            const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
-            const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
-            if (lo > t0) t0 = lo;
-            if (hi < t1) t1 = hi;
+        if (any) {
+            double u[N];
+            blob_vec<N>(blob, p + k * (N + 2), u);
+            po[k] = v_dot<N>(u, o);
+            const double a = po[k] - blob[p + k * (N + 2) + N];
+            const double d = v_dot<N>(u, v);
+            const double h = blob[p + k * (N + 2) + N + 1];
+            if (fabs(d) < 1e-200) {
+                inv[k] = 0.0;
+                if (fabs(a) > h) ok = false;        // parallel to the slab and outside it
+            } else {
+                inv[k] = slab_rcp(d);
+                const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                if (lo > t0) t0 = lo;
+                if (hi < t1) t1 = hi;
+            }
+            if (k >= 1) {
+                ok = ok && slab_interval_holds(t0, t1);
+                any = __ballot(ok) != 0ull;
+            }
         }
     }
-    if (!(ok && t0 <= t1)) return 0;
+    if (!any || !ok) return 0;
     if (!face_boxes) return -1;
     const int fr = p + N * (N + 2);
     unsigned long long live = 0ull;
@@ -722,20 +750,27 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
         const int q = fr + 1 + f * 2 * N;
         double f0 = 0.0, f1 = NDT_DBL_MAX;
         bool fok = true;
+        bool fany = true;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const double a = po[k] - blob[q + 2 * k];
-            const double h = blob[q + 2 * k + 1];
-            if (inv[k] == 0.0) {
-                if (fabs(a) > h) fok = false;
-            } else {
-                const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
-                const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
-                if (lo > f0) f0 = lo;
-                if (hi < f1) f1 = hi;
+            if (fany) {
+                const double a = po[k] - blob[q + 2 * k];
+                const double h = blob[q + 2 * k + 1];
+                if (inv[k] == 0.0) {
+                    if (fabs(a) > h) fok = false;
+                } else {
+                    const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                    const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                    if (lo > f0) f0 = lo;
+                    if (hi < f1) f1 = hi;
+                }
+                if ((k & 1) && k + 1 < N) {
+                    fok = fok && slab_interval_holds(f0, f1);
+                    fany = __ballot(fok) != 0ull;
+                }
             }
         }
-        if (fok && f0 <= f1) live |= 1ull << f;
+        if (fany && fok && slab_interval_holds(f0, f1)) live |= 1ull << f;
     }
     return (long long)(live & (unsigned long long)__double_as_longlong(blob[fr]));
 }

@@ -271,8 +271,12 @@ NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const Sce
         const unsigned long long fire = cldu(ws.sh_mask + g);
         const unsigned long long key = rg.sample_keys ? cldu(ws.rng_key + g) : 0ull;
         int n_shadow = 0;
-        int seg = -1;
-        for (int li = 0; li < sd.n_lights; ++li) {
+        // every lane walks its own lights -- those that fired, and the ambient ones, in the list's order (shade_finish_node)
+        unsigned long long ambient = 0ull;
+        for (int li = 0; li < sd.n_lights; ++li)
+            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) ambient |= 1ull << li;      // wave-uniform
+        for (unsigned long long todo = fire | ambient; todo != 0ull; todo &= todo - 1ull) {
+            const int li = __ffsll((long long)todo) - 1;
             const int w = light_word(sd, li);
             const int ltype = blob_int(mat, w, 0);
             const double lr_ = mat[w + 1], lg_ = mat[w + 2], lb_ = mat[w + 3];
@@ -282,8 +286,7 @@ NDT_DEV bool stream_light_batch(const double *blob, const double *mat, const Sce
                 cb += hit_b * lb_;
                 continue;
             }
-            ++seg;
-            if (!((fire >> li) & 1ull)) continue;
+            const int seg = __popcll(~ambient & ((1ull << li) - 1ull));
             const long long slot = (long long)seg * sa.seg_cap + cldi(ws.sh_idx + (long long)seg * ws.cap + g);
             int type;
             double lgt_pos[N], rev_light[N], light_vec[N], so[N], light_hit_normal[N];
@@ -396,14 +399,16 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
                 if (light_setup(mat, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss, node_key)) fire |= 1ull << li;
             }
         }
-        // lane s learns how many lanes fire segment s's light
+        // lane s learns which lanes fire segment s's light (and so how many)
         int my_total = 0, seg = 0;
+        unsigned long long my_vote = 0ull, ambient = 0ull;
         for (int li = 0; li < sd.n_lights; ++li) {
-            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;      // wave-uniform
+            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) { ambient |= 1ull << li; continue; }      // wave-uniform
             const unsigned long long vote = __ballot((fire >> li) & 1ull);
-            if (lane == seg) my_total = __popcll(vote);
+            if (lane == seg) my_vote = vote;
             ++seg;
         }
+        my_total = __popcll(my_vote);
         if (shaded) cstu(ws.sh_mask + g, fire);
         // ---- get_ray_color, ndt.c:381-430: reflection / refraction children
         bool want_refl = false, want_refr = false;
@@ -506,13 +511,19 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
             for (int d = 32; d > 0; d >>= 1) lvl = max(lvl, __shfl_xor(lvl, d, 64));
             stats.max_level = max(stats.max_level, lvl);
         }
-        // ---- the shadow rays, into their segments
-        seg = 0;
-        for (int li = 0; li < sd.n_lights; ++li) {
-            if (blob_int(mat, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
-            const bool fires = (fire >> li) & 1ull;
-            const unsigned long long vote = __ballot(fires);
+        // ---- the shadow rays, into their segments: every lane walks the lights it fires (shade_emit_node)
+        int rounds = __popcll(fire);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) rounds = max(rounds, __shfl_xor(rounds, d, 64));
+        unsigned long long todo = fire;
+        for (int r = 0; r < rounds; ++r) {
+            const bool fires = todo != 0ull;
+            const int li = fires ? __ffsll((long long)todo) - 1 : 0;
+            todo &= todo - 1ull;
+            const int seg = __popcll(~ambient & ((1ull << li) - 1ull));
             const int sbase = __shfl(my_base, seg, 64);
+            const unsigned long long vote = ((unsigned long long)(unsigned int)__shfl((int)(my_vote >> 32), seg, 64) << 32)
+                                            | (unsigned long long)(unsigned int)__shfl((int)my_vote, seg, 64);
             if (fires) {
                 int type;
                 double lgt_pos[N], rev_light[N], light_vec[N], so[N];
@@ -531,7 +542,6 @@ NDT_DEV void stream_shade_batch(const double *blob, const double *mat, const Sce
                 cst(ws.slim + slot, ss.dist_limit);
                 csti(sa.sowner + slot, (int)g);
             }
-            ++seg;
         }
         // the batch's unanswered shadow rays: counted BEFORE any of them can be answered
         if (n_sh_batch > 0 && lane == 0) atomicAdd(sa.sh_pending + nb, n_sh_batch);
