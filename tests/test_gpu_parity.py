@@ -810,7 +810,7 @@ def test_bench_line_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mray/s" and c["sample"]
     c1 = d["cpu_baseline_t1"]
     assert c1["cores"] == 1 and c1["value"] > 0 and c1["unit"] == "Mray/s"
-    assert d["ms_per_step_host_rgba8"] > d["ms_per_step"] * 0.5
+    assert d["ms_per_step_host_rgba8"] > 0 and d["ms_per_step_host_rgba8_pipelined"] > 0       # (timings of three steps: no relation asserted)
 
 
 @pytest.mark.gpu

@@ -159,3 +159,68 @@ def test_cull_changes_nothing_on_the_device(oracle, name):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)
         assert np.array_equal(a, d)
+
+
+def axis_rays(fs, seed):
+    """Rays the slab arithmetic finds hardest: along the axes of every hull box's frame (u_k.v is 1 for one slab and a
+    rounding error -- 1e-17, its reciprocal 1e17 -- or exactly 0 for the others), through the places faces can be hit and
+    just outside the box; rays that start inside the box; and rays that graze a slab's surface at a shallow angle."""
+    from ndt_amd.hip import hcube_hull_box, hcube_face_boxes
+    rng = np.random.default_rng(seed)
+    n = fs.dims
+    rays = []
+    for h in hcubes(fs):
+        box = hcube_hull_box(fs, h)
+        if box is None:
+            continue
+        ax, c, half = box
+        faces = hcube_face_boxes(fs, h)
+        spots = [c + rng.uniform(-1.02, 1.02, n) * half for _ in range(40)]
+        if faces is not None:
+            centre, fhalf, live = faces
+            spots += [centre[f] + rng.uniform(-1, 1, n) * fhalf[f] for f in np.flatnonzero(live)[:24]]
+        for s in spots:
+            p = s @ ax                                                      # frame coordinates -> world
+            for k in range(n):
+                for sign in (1.0, -1.0):
+                    d = sign * ax[k]
+                    rays.append(np.concatenate([p - d * rng.uniform(3, 9), d, [-1.0]]))
+                    rays.append(np.concatenate([p, d, [-1.0]]))             # starts where it aims
+                    g = d + 1e-3 * rng.normal(0, 1, n)                      # shallow against the other slabs
+                    g /= np.linalg.norm(g)
+                    rays.append(np.concatenate([p - g * rng.uniform(3, 9), g, [rng.uniform(2, 20)]]))
+        # exactly along the world's axes too (dot products with exact zeros)
+        for k in range(n):
+            e = np.zeros(n)
+            e[k] = 1.0
+            p = (c + rng.uniform(-1, 1, n) * half) @ ax
+            rays.append(np.concatenate([p - 5 * e, e, [-1.0]]))
+    return np.array(rays)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_rays_along_the_frame_axes_and_from_inside_the_box(oracle, name):
+    """The hull test takes 1/(u_k.v) from the hardware's reciprocal (ndt_device.hpp:slab_rcp) and lets its comparisons
+    give by 2^-30: the extreme quotients must still never cull what the reference hits."""
+    from ndt_amd.hip import NdtHip
+    fs = golden(name).scene
+    if not hcubes(fs):
+        pytest.skip("no hcube in this scene")
+    rays = axis_rays(fs, seed=29)
+    if len(rays) == 0:
+        pytest.skip("no hcube of this scene has a hull box")
+    want = oracle.trace(fs, rays)
+    gpu = NdtHip(0)
+    try:
+        gpu.upload_scene(fs)
+        got = gpu.trace_rays(rays)
+        gpu.set_option("hull_box", 0)
+        gpu.upload_scene(fs)
+        plain = gpu.trace_rays(rays)
+    finally:
+        gpu.close()
+    for a, b, c in zip(got, plain, want):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)
+    assert (want[0] >= 0).sum() > 10
