@@ -70,6 +70,10 @@ def algorithmic_bytes_per_ray(dims):
     return 64 * dims + 168
 
 
+def f64_frames_in_flight(torch, height, width):
+    return torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")
+
+
 def committed_profile(workload, width, height):
     """The committed rocprofv3 session of this very command (profiles/profile_workload.sh -> profiles/make_profile_json.py):
     HBM bytes per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes (x2 on FETCH_SIZE per the gfx950
@@ -416,6 +420,31 @@ def main():
             line["ms_per_step_host_rgba8_pipelined"] = (time.perf_counter() - t1) / n_seq * 1e3
             check, _ = gpu.render_rgba8(width, height, depth)
             line["host_rgba8_pipelined_bytes_identical"] = bool(np.array_equal(pinned[(n_seq - 1) & 1].numpy(), check))
+            # ... and with TWO frames in flight (two contexts, two host threads -- the host program's -j 2, the reference's
+            # frame-level parallelism): the launches of one frame fill the tails of the other's.  Not the headline: a frame alone
+            # takes ms_per_step.  2 x 10 frames, images left in HBM like the timed steps.
+            import threading
+            second = NdtHip(local_rank)
+            second.upload_scene(fs)
+            pair = [(gpu, f64_frames_in_flight(torch, height, width)), (second, f64_frames_in_flight(torch, height, width))]
+
+            def frames(ctx, buf, n):
+                for _ in range(n):
+                    ctx.render_device(buf.data_ptr(), width, height, depth)
+
+            for ctx, buf in pair:
+                frames(ctx, buf, 2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ths = [threading.Thread(target=frames, args=(ctx, buf, 10)) for ctx, buf in pair]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            line["ms_per_step_two_frames_in_flight"] = (time.perf_counter() - t1) / 20 * 1e3
+            line["two_frames_in_flight_identical"] = bool(torch.equal(pair[0][1], pair[1][1]))
+            second.close()
         elif args.scaling == "strong" and not rehearsal:
             # the time this frame takes on ONE GPU (rank 0's, alone: the other ranks wait at the barrier below)
             whole = torch.zeros((height, width, 4), dtype=torch.float64, device="cuda")

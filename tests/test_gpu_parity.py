@@ -811,6 +811,8 @@ def test_bench_line_contract():
     c1 = d["cpu_baseline_t1"]
     assert c1["cores"] == 1 and c1["value"] > 0 and c1["unit"] == "Mray/s"
     assert d["ms_per_step_host_rgba8"] > 0 and d["ms_per_step_host_rgba8_pipelined"] > 0       # (timings of three steps: no relation asserted)
+    assert d["host_rgba8_pipelined_bytes_identical"] is True
+    assert d["ms_per_step_two_frames_in_flight"] > 0 and d["two_frames_in_flight_identical"] is True
 
 
 @pytest.mark.gpu
