@@ -294,6 +294,7 @@ int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
  *                     one persistent launch), 3 hybrid -- DESIGN.md section 3; the environment takes the words
  *   "hybrid_level"    hybrid: the bounce from which on the frame kernel renders (default 2)
  *   "stream_below"    auto: passes of up to this many primaries go to the streaming frame kernel
+ *   "stream_below_list"  ... and passes over a list of samples (recursive anti-aliasing) of up to this many (default 30 000)
  *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
  *   "stream_fused"            0: the frame kernel between a k_primary and a k_finish_pixels launch instead of making its
  *                                primaries and writing its pixels itself (tests prove it neutral)

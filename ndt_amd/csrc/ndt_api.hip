@@ -59,7 +59,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ctx->device = device;
     {
         // the environment is read here, once: nothing on the render or upload path looks at it
-        static const char *const names[] = { "hybrid_level", "stream_below", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "multi_path", "sample_seed", "stream_fused", "shade_pair", "debug_levels",
+        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "multi_path", "sample_seed", "stream_fused", "shade_pair", "debug_levels",
                                              "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
         if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
@@ -137,6 +137,7 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
         ctx->pipeline = (int)value;
     } else if (!strcmp(name, "hybrid_level")) ctx->hybrid_level = (int)value;
     else if (!strcmp(name, "stream_below")) ctx->stream_below = value;
+    else if (!strcmp(name, "stream_below_list")) ctx->stream_below_list = value;
     else if (!strcmp(name, "hull_box")) ctx->hull_box = on;
     else if (!strcmp(name, "face_box")) ctx->face_box = on;
     else if (!strcmp(name, "item_sets")) ctx->item_sets = on;

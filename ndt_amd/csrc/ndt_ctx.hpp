@@ -78,6 +78,7 @@ struct ndt_hip_ctx {
     int pipeline = 0;               // 0 auto, 1 levels, 2 stream, 3 hybrid
     int hybrid_level = 2;           // hybrid: the bounce from which on the frame kernel renders (NDT_HIP_HYBRID_LEVEL)
     long long stream_below = 1000000;       // where the two cross on the benchmark scene (profiles/r03_frame_time_vs_size_*.txt: 1280x720 stream 0.918 / levels 0.965 ms, 1408x792 1.054 / 1.045; the r::8 shard of a 3840x2160 frame, 1.04 M primaries: 0.977 per bounce, 1.00 streamed)
+    long long stream_below_list = 30000;    // ... for passes over a list of samples (-a): 1080p -a 20,4 of the benchmark scene 27.6 -> 24.0 ms, balls 14.0 -> 12.7
     bool use_stream = false;        // the choice for the pass being rendered
     StreamArgs sa{};
     // ndt_hip_set_option / NDT_HIP_* at context creation (include/ndt_hip.h)

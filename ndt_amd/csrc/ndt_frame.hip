@@ -475,7 +475,9 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
     // (the gate prepass of trace_kd: the scene description a pass's kernels get carries the gated items only when it is on)
     SceneDesc sd_pass = ctx->sd;
     if (ctx->gate_prepass == 0 || (ctx->gate_prepass == 2 && n_primary > ctx->gate_prepass_below)) sd_pass.gate_bits = 0ull;
-    const long long stream_upto = ctx->stream_below;
+    // (a pass over a LIST of image positions -- recursive anti-aliasing's samples, all of them on the edges the first pass found:
+    // 15 rays a sample where a frame has 2.4 a pixel -- crosses over much earlier: profiles/r03_modes_1080p.txt)
+    const long long stream_upto = rg.samples ? ctx->stream_below_list : ctx->stream_below;
     ctx->use_stream = ctx->pipeline == 2 || (ctx->pipeline == 0 && n_primary <= stream_upto);
     const bool hybrid = !ctx->use_stream && ctx->pipeline == 3 && ctx->hybrid_level >= 1 && rg.max_depth > ctx->hybrid_level;
     // (auto only) the frame kernel keeps one shadow slot per node AND light for the whole frame: with many lights that can
