@@ -37,10 +37,17 @@ __device__ __forceinline__ void aa_avg4(const double *p1, const double *p2, cons
 __global__ void k_aa_seed(const double *pass1, int width, int rows, int row_begin, int row_step, int row_pair, double threshold,
                           double *out, AaTask *tasks, int *counter)
 {
-    const long long idx_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = idx_raw < (long long)rows * width;
-    const long long idx = in_range ? idx_raw : 0;
-    const int l = (int)(idx / width), i = (int)(idx % width);
+    // a wavefront looks at an 8 x 8 tile of pixels, the tiles in row-major order: the tasks it appends -- and, roughly, those
+    // of the wavefronts around it -- then lie together in the image and their samples' rays in one batch run through the same
+    // part of the scene (pixel after pixel along an image row they came from every edge the row crosses)
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tiles_x = (width + 7) / 8;
+    const long long tile = tid >> 6;
+    const int lane = (int)(tid & 63);
+    const int i_raw = (int)(tile % tiles_x) * 8 + (lane & 7), l_raw = (int)(tile / tiles_x) * 8 + (lane >> 3);
+    const bool in_range = i_raw < width && l_raw < rows;
+    const int i = in_range ? i_raw : 0, l = in_range ? l_raw : 0;
+    const long long idx = (long long)l * width + i;
     const int r0 = row_pair ? 2 * l : l, r1 = r0 + 1;
     const long long w1 = width + 1;
     const double *p1 = pass1 + (r0 * w1 + i) * 4, *p2 = p1 + 4;
@@ -91,15 +98,19 @@ __global__ void k_aa_split(AaTask *tasks, int n_tasks, double step, double thres
     // ... and in the order the recursive call receives them as p1..p4 (ndt.c:687, 692, 697, 702)
     const double *qc[4][4] = { { T.p[0], p6, p7, p5 }, { p6, T.p[1], p5, p8 }, { p7, p5, T.p[2], p9 }, { p5, p8, p9, T.p[3] } };
     const double qx[4] = { T.x, T.x + hs, T.x, T.x + hs }, qy[4] = { T.y, T.y, T.y + hs, T.y + hs };
+    // which quarters are refined; then ONE reservation for the workgroup (block_append_n), a task's children side by side
+    unsigned refine_mask = 0;
     for (int k = 0; k < 4; ++k) {
         double var = 0.0, avg[4];
         aa_avg4(qa[k][0], qa[k][1], qa[k][2], qa[k][3], avg, &var);
         if (in_range)
             for (int ch = 0; ch < 4; ++ch) T.sp[k][ch] = avg[ch];
-        const bool refine = in_range && var > threshold;
-        const int c = wave_append(next_counter, refine);
-        if (refine) {
-            AaTask &C = next[c];
+        if (in_range && var > threshold) refine_mask |= 1u << k;
+    }
+    int c = block_append_n(next_counter, __popc(refine_mask));
+    for (int k = 0; k < 4; ++k) {
+        if (refine_mask & (1u << k)) {
+            AaTask &C = next[c++];
             C.x = qx[k];
             C.y = qy[k];
             for (int m = 0; m < 4; ++m)
@@ -243,7 +254,7 @@ int ndt_impl::render_antialiased(ndt_hip_ctx *ctx, const ndt_render_params *p, v
     std::vector<int> level_count;
     AaTask *t0 = nullptr;
     if ((rc = buf.get(&t0, (size_t)n_out))) return rc;
-    hipLaunchKernelGGL(k_aa_seed, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, pass1, W, rows, p->row_begin, p->row_step,
+    hipLaunchKernelGGL(k_aa_seed, dim3((unsigned)((((long long)((W + 7) / 8) * ((rows + 7) / 8)) * 64 + 255) / 256)), dim3(256), 0, s, pass1, W, rows, p->row_begin, p->row_step,
                        g1.row_pair, threshold, (double *)d_rgba, t0, counters);
     int n_tasks = 0;
     HIP_TRY(hipMemcpyAsync(&n_tasks, counters, sizeof(int), hipMemcpyDeviceToHost, s));

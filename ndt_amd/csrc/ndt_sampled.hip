@@ -112,7 +112,7 @@ __global__ void k_ns_accumulate(const int *active, int n_active, int per, const 
         t[4] = clr_diff;
         taken[pix] += used;
     }
-    const int slot = wave_append(next_count, go_on);
+    const int slot = block_append(next_count, go_on);
     if (go_on) next[slot] = pix;
 }
 
@@ -139,7 +139,15 @@ __global__ void k_ns_finish(const double *acc, const int *taken, double *rgba, d
         used = (unsigned long long)taken[i];
     }
     for (int d = 32; d > 0; d >>= 1) used += __shfl_down(used, d, 64);
-    if ((threadIdx.x & 63) == 0 && used) atomicAdd(used_total, used);
+    // one atomic a workgroup (see block_append)
+    __shared__ unsigned long long wave_used[16];
+    if ((threadIdx.x & 63) == 0) wave_used[threadIdx.x >> 6] = used;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) sum += wave_used[w];
+        if (sum) atomicAdd(used_total, sum);
+    }
 }
 
 // One eye's image (or the whole image, for the modes that split it by position).  eye: 0 left, 1 centre, 2 right; stereo: what
@@ -193,7 +201,6 @@ static int render_sampled_eye(ndt_hip_ctx *ctx, const ndt_render_params *p, int 
             if ((rc = buf.get(&keys, cap_samples + 64))) return rc;
             if (d_depth && (rc = buf.get(&sdepth, cap_samples + 64))) return rc;
         }
-        const unsigned g_act = (unsigned)((n_active + 255) / 256);
         hipLaunchKernelGGL(k_ns_samples, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, list[flip], n_active, (int)per, W,
                            p->row_begin, p->row_step, round, ctx->aperture_radius, (p->samples > 1 && !sl) ? 1 : 0, (p->samples > 1 || sl) ? 1 : 0,
                            // (the jitter is 1/width x 1/height of the IMAGE; a frame-packed eye image is 1080 lines of its 2205, ndt.c:482-483, 629)
@@ -221,7 +228,7 @@ static int render_sampled_eye(ndt_hip_ctx *ctx, const ndt_render_params *p, int 
         if ((rc = render_pass(ctx, gs, p->profile != 0, colours, st, d_depth ? sdepth : nullptr))) return rc;
         add_stats(total, st);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_ns_accumulate, dim3(g_act), dim3(256), 0, s, list[flip], n_active, (int)per, colours, d_depth ? sdepth : nullptr,
+        hipLaunchKernelGGL(k_ns_accumulate, dim3((unsigned)((n_active + 1023) / 1024)), dim3(1024), 0, s, list[flip], n_active, (int)per, colours, d_depth ? sdepth : nullptr,
                            round, p->samples, W, p->row_begin, p->row_step, blank_from, blank_to, acc, taken, list[flip ^ 1], counter);
         HIP_TRY(hipMemcpyAsync(&n_active, counter, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -231,7 +238,7 @@ static int render_sampled_eye(ndt_hip_ctx *ctx, const ndt_render_params *p, int 
     unsigned long long *used_total = nullptr, used_host = 0;
     if ((rc = buf.get(&used_total, 1))) return rc;
     HIP_TRY(hipMemsetAsync(used_total, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_ns_finish, dim3(g_all), dim3(256), 0, s, acc, taken, (double *)d_rgba, (double *)d_depth, n_pixels, used_total);
+    hipLaunchKernelGGL(k_ns_finish, dim3((unsigned)((n_pixels + 1023) / 1024)), dim3(1024), 0, s, acc, taken, (double *)d_rgba, (double *)d_depth, n_pixels, used_total);
     HIP_TRY(hipMemcpyAsync(&used_host, used_total, sizeof(used_host), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));

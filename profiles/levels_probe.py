@@ -13,6 +13,7 @@ ap.add_argument("--scene", default="c3_random4d")
 ap.add_argument("--res", default="1920x1080")
 ap.add_argument("--depth", type=int, default=4)
 ap.add_argument("--drop-type", default="")
+ap.add_argument("--aa", default="", help="diff,depth: recursive anti-aliasing (every pass prints)")
 ap.add_argument("--opt", action="append", default=[], help="name=value for ndt_hip_set_option, before the scene is uploaded")
 a = ap.parse_args()
 fs = load_scene("tests/golden/%s.ndtscene.gz" % a.scene)
@@ -35,8 +36,9 @@ g.set_option("pipeline", 1)             # the per-bounce kernels: what the phase
 for kv in a.opt:
     g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 g.upload_scene(fs)
-for i in range(3):
+for i in range(3 if not a.aa else 1):
     g.render(w, h, a.depth)
 g.set_option("debug_levels", 1)
-out, st = g.render(w, h, a.depth, profile=1)
+aa = tuple(int(x) for x in a.aa.split(",")) if a.aa else None
+out, st = g.render(w, h, a.depth, profile=1, aa=aa)
 print(st.as_dict())
