@@ -32,7 +32,7 @@ extern "C" {
 /* Dimensions the gfx950 kernels are instantiated for.  The reference accepts any N >= 3
  * (ndt.c:1450 `-d`); BASELINE.json's configs span 3..8. */
 #define NDT_MIN_DIMS 3
-#define NDT_MAX_DIMS 10
+#define NDT_MAX_DIMS 12
 #define NDT_MAX_LIGHTS 64
 
 #define NDT_OK              0

@@ -36,6 +36,8 @@ static const NdtKernelTable *table_for(int dims)
     case 8: return ndt_kernel_table_8();
     case 9: return ndt_kernel_table_9();
     case 10: return ndt_kernel_table_10();
+    case 11: return ndt_kernel_table_11();
+    case 12: return ndt_kernel_table_12();
     default: return nullptr;
     }
 }

@@ -210,6 +210,8 @@ extern "C" const NdtKernelTable *ndt_kernel_table_7();
 extern "C" const NdtKernelTable *ndt_kernel_table_8();
 extern "C" const NdtKernelTable *ndt_kernel_table_9();
 extern "C" const NdtKernelTable *ndt_kernel_table_10();
+extern "C" const NdtKernelTable *ndt_kernel_table_11();
+extern "C" const NdtKernelTable *ndt_kernel_table_12();
 
 #define NDT_TRACE_BLOCK 256
 // The global-memory tier (visit masks in the slab, scene in global memory: the 6-D .. 8-D hypercubes) launches

@@ -11,7 +11,7 @@ import gzip
 import numpy as np
 
 ABI_VERSION = 3
-MIN_DIMS, MAX_DIMS = 3, 10
+MIN_DIMS, MAX_DIMS = 3, 12
 
 OBJ_TYPES = ["sphere", "hplane", "hdisk", "cylinder", "hcylinder", "orthotope", "hcube", "hfacet", "facet"]
 OBJ_TYPE_ID = {name: i for i, name in enumerate(OBJ_TYPES)}

@@ -114,9 +114,9 @@ def golden(name):
 
 SMALL_CASES = ["c1_hypercube3d", "c1_hypercube3d_f37", "c2_balls4d", "c3_random4d", "c5_hypercube4d",
                "c5_hypercube5d", "c5_hypercube6d", "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror",
-               "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "c5_hypercube9d", "c5_hypercube9d"]
+               "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "zoo11d", "zoo12d", "c5_hypercube9d"]
 KAT_CASES = ["c1_hypercube3d", "c2_balls4d", "c3_random4d", "c5_hypercube4d", "c5_hypercube5d", "c5_hypercube6d",
-             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "c5_hypercube9d",
+             "c5_hypercube7d", "c5_hypercube8d", "zoo4d", "zoo3d_mirror", "zoo5d_f2", "zoo6d", "zoo9d", "zoo10d", "zoo11d", "zoo12d", "c5_hypercube9d",
              # 8192 queries each, half of them aimed at the items of every kd leaf: the global-memory tier
              "kat_hypercube6d", "kat_hypercube7d", "kat_hypercube8d"]
 # every BASELINE config at its stated size, 8-bit like the reference's PNG: configs[0] 256x256, [1] and [2] 1920x1080,

@@ -53,6 +53,9 @@ CASES = {
     # hcubes make a 12 MB / 42 MB scene file in 9-D / 10-D and its camera sees none of it: not kept.)
     "zoo9d": dict(scene="parity_zoo", dims=9, res=(40, 24), depth=5, fb=True, kat=512),
     "zoo10d": dict(scene="parity_zoo", dims=10, res=(40, 24), depth=5, fb=True, kat=512),
+    # 11-D and 12-D: the zoo without its hcube (164 k / 500 k nested faces there)
+    "zoo11d": dict(scene="parity_zoo", dims=11, res=(40, 24), depth=5, fb=True, kat=512, config="nohcube"),
+    "zoo12d": dict(scene="parity_zoo", dims=12, res=(40, 24), depth=5, fb=True, kat=512, config="nohcube"),
     "c5_hypercube9d": dict(scene="hypercube", dims=9, res=(24, 14), depth=128, fb=True, kat=1024, kat_aimed=True),
     # tests/scenes/parity_zoo.c (this repo's own scene program, compiled against the reference):
     # spot light, LIGHT_AMBIENT entry + scn->ambient, glass with total internal reflection, finite

@@ -209,17 +209,20 @@ int scene_setup(scene *scn, int dims, int frame, int frames, char *config)
     set_axis(&d, dims, 1.0, 7.0, -1.5, 0.5);
     object_add_dir(o, &d);
 
-    /* an hcube with skewed, non-unit directions */
-    o = add(scn, dims, "hcube", 0.2, 0.7, 0.7, 0.3);
-    set_axis(&p, dims, 1.0, -2.5, -9.0, 0.5);
-    object_add_pos(o, &p);
-    for (int i = 0; i < dims; ++i) {
-        vectNd_reset(&d);
-        vectNd_set(&d, i, 1.0);
-        vectNd_set(&d, (i + 1) % dims, 0.15);
-        vectNd_unitize(&d);
-        object_add_dir(o, &d);
-        object_add_size(o, 3.0 + 0.5 * i);
+    /* an hcube with skewed, non-unit directions (config "nohcube": left out -- it has every m-face for m = 2 .. N-1 as a
+     * nested object, half a million of them in 12-D) */
+    if (!(config && strstr(config, "nohcube"))) {
+        o = add(scn, dims, "hcube", 0.2, 0.7, 0.7, 0.3);
+        set_axis(&p, dims, 1.0, -2.5, -9.0, 0.5);
+        object_add_pos(o, &p);
+        for (int i = 0; i < dims; ++i) {
+            vectNd_reset(&d);
+            vectNd_set(&d, i, 1.0);
+            vectNd_set(&d, (i + 1) % dims, 0.15);
+            vectNd_unitize(&d);
+            object_add_dir(o, &d);
+            object_add_size(o, 3.0 + 0.5 * i);
+        }
     }
 
     /* hfacets: one with interpolated vertex normals, one with the computed normal */
