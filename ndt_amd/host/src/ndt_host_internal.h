@@ -57,6 +57,7 @@ typedef struct {
 /* Builds bounds + kd-tree exactly like ndt.c:1899-1908, aims the camera (ndt.c:1925) and
  * flattens.  Returns 0, or -1 with a message in `err` when the scene cannot go to the device. */
 int ndt_flatten_scene(scene *scn, ndt_flat_builder *fb, char *err, int err_len);
+int ndt_flatten_scene_mt(scene *scn, ndt_flat_builder *fb, char *err, int err_len, int threads);
 void ndt_flat_builder_free(ndt_flat_builder *fb);
 int ndt_write_ndtscene(const ndt_flat_scene *fs, const char *name, const char *path);
 

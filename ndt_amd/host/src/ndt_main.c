@@ -413,7 +413,7 @@ int main(int argc, char **argv)
         if (dump_path) {
             char err[256];
             ndt_flat_builder fb;
-            if (ndt_flatten_scene(scn, &fb, err, sizeof(err)) != 0) { fprintf(stderr, "%s\n", err); return 1; }
+            if (ndt_flatten_scene_mt(scn, &fb, err, sizeof(err), threads) != 0) { fprintf(stderr, "%s\n", err); return 1; }
             if (i == last || i == frames - 1) ndt_write_ndtscene(&fb.fs, scn->name, dump_path);
             ndt_flat_builder_free(&fb);
             scene_free(scn);

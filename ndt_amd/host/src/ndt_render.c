@@ -60,11 +60,11 @@ int ndt_render_image_aa(scene *scn, int width, int height, int threads, int aa_d
 }
 
 static int render_any(scene *scn, int width, int height, int samples, int aa_diff, int aa_depth, int stereo, int specular,
-                      int max_optic_depth, int format, void *out, double *depth)
+                      int max_optic_depth, int format, void *out, double *depth, int threads)
 {
     char err[256];
     ndt_flat_builder fb;
-    if (ndt_flatten_scene(scn, &fb, err, sizeof(err)) != 0) {
+    if (ndt_flatten_scene_mt(scn, &fb, err, sizeof(err), threads) != 0) {
         fprintf(stderr, "ndt_render_image: %s\n", err);
         ndt_flat_builder_free(&fb);
         return 0;
@@ -108,13 +108,12 @@ static int render_any(scene *scn, int width, int height, int samples, int aa_dif
 int ndt_render_image_full(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
                           int specular, int max_optic_depth, double *rgba, double *depth)
 {
-    (void)threads;      /* the pthread fan-out of ndt.c:949-975 is the GPU's job now */
-    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_F64, rgba, depth);
+    /* (the pthread fan-out of ndt.c:949-975 is the GPU's job now; `threads` fits the scene's bounding spheres in parallel) */
+    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_F64, rgba, depth, threads);
 }
 
 int ndt_render_image_rgba8(scene *scn, int width, int height, int samples, int threads, int aa_diff, int aa_depth, int stereo,
                            int specular, int max_optic_depth, unsigned char *rgba8)
 {
-    (void)threads;
-    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_RGBA8, rgba8, NULL);
+    return render_any(scn, width, height, samples, aa_diff, aa_depth, stereo, specular, max_optic_depth, NDT_IMAGE_RGBA8, rgba8, NULL, threads);
 }
