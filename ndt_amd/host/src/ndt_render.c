@@ -1,6 +1,7 @@
 /* ndt_render.c -- render_image (reference ndt.c:900) for this host model: flatten, upload,
  * render on the GPU through the C ABI of include/ndt_hip.h.  No CPU rendering exists here. */
 #include "ndt_host_internal.h"
+#include <time.h>
 
 /* GPU contexts (stream + workspace) of the calling host thread: frames rendered from different threads overlap on the
  * GPU, or run on different GPUs (ndt_render_use_device); one frame may be spread over several (ndt_render_use_devices) */
@@ -64,14 +65,21 @@ static int render_any(scene *scn, int width, int height, int samples, int aa_dif
 {
     char err[256];
     ndt_flat_builder fb;
+    /* NDT_HOST_TIMING=1: where a frame's host time goes (stderr) */
+    static int timing = -1;
+    if (timing < 0) timing = getenv("NDT_HOST_TIMING") != NULL;
+    struct timespec ts0, ts1, ts2, ts3;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &ts0);
     if (ndt_flatten_scene_mt(scn, &fb, err, sizeof(err), threads) != 0) {
         fprintf(stderr, "ndt_render_image: %s\n", err);
         ndt_flat_builder_free(&fb);
         return 0;
     }
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int ok = have_contexts();
     for (int k = 0; ok && k < g_n_ctx; ++k)
         if (ndt_hip_upload_scene(g_ctx[k], &fb.fs) != NDT_OK) ok = 0;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &ts2);
     if (ok) {
         ndt_render_params p;
         memset(&p, 0, sizeof(p));
@@ -99,6 +107,12 @@ static int render_any(scene *scn, int width, int height, int samples, int aa_dif
         }
     }
     if (!ok) fprintf(stderr, "ndt_render_image: %s\n", ndt_hip_last_error());
+    if (timing) {
+        clock_gettime(CLOCK_MONOTONIC, &ts3);
+#define NDT_MS(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+        fprintf(stderr, "ndt_render_image: bounds + kd-tree + flatten %.2f ms, upload %.2f ms, render + image to host %.2f ms\n",
+                NDT_MS(ts0, ts1), NDT_MS(ts1, ts2), NDT_MS(ts2, ts3));
+    }
     ndt_flat_builder_free(&fb);
     return ok;
 }
