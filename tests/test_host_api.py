@@ -66,8 +66,10 @@ def _fixture_text(name):
         return f.read()
 
 
-def _dump(driver, scene_so, dims, frame, out, config=None, v2=False):
+def _dump(driver, scene_so, dims, frame, out, config=None, v2=False, threads=None):
     cmd = [driver, "-s", scene_so, "-d", str(dims), "-f", "%d:%d" % (frame, frame), "--dump-scene", out]
+    if threads:
+        cmd += ["-t", str(threads)]
     if config:
         cmd += ["-u", config]
     env = dict(os.environ)
@@ -102,6 +104,19 @@ def test_reference_built_scene_binaries_load_unchanged(driver, tmp_path, name):
     prog, dims, frame, config = CASES[name]
     so = os.path.join(REF_BIN, prog + ".so")
     assert _dump(driver, so, dims, frame, str(tmp_path / "out.ndtscene"), config, name in V2) == _fixture_text(name)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_BIN), reason="oracle/_ref not built (make -C oracle ref)")
+@pytest.mark.parametrize("name", ["c5_hypercube6d", "c5_hypercube7d", "c3_random4d"])
+def test_sphere_fits_on_several_threads_give_the_same_scene(driver, tmp_path, name):
+    """`-t T` fits the lazily fitted bounding spheres on T threads ahead of the flattening loops (ndt_flatten.c): the scene
+    that comes out -- spheres, kd-tree, everything -- is the fixture's, whatever T.  (The 6-D / 7-D hypercubes are also what
+    exercises the kd-tree build's sorted split scores with inverted boxes: infinite hcylinders among a cluster's children.)"""
+    prog, dims, frame, config = CASES[name]
+    so = os.path.join(REF_BIN, prog + ".so")
+    for threads in (2, 7, 16):
+        assert _dump(driver, so, dims, frame, str(tmp_path / ("out%d.ndtscene" % threads)), config, name in V2,
+                     threads=threads) == _fixture_text(name)
 
 
 @pytest.mark.gpu
