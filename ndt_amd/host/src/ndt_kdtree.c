@@ -165,21 +165,48 @@ static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, cons
     double split_pos = 0.0, score = -DBL_MAX, best = -DBL_MAX;
     const int sorted = order != NULL && n >= KD_SORTED_MIN;
     double *los = sorted ? (double *)malloc((size_t)n * sizeof(double)) : NULL, *ups = sorted ? (double *)malloc((size_t)n * sizeof(double)) : NULL;
+    /* scores of the candidates of the regular items, by item (filled per dimension by two sweeps) */
+    int *left_of = sorted ? (int *)malloc((size_t)4 * n * sizeof(int)) : NULL;     /* [4 * i + 0 .. 3] for ids[i]: left, right of its lower / upper candidate */
+    int *slot_of = NULL;
+    if (sorted) {
+        /* position of an item in ids[]: through the tree-sized scratch behind `side` would need another array; a node-sized
+         * map keyed by the order arrays is enough -- the sweeps write through it */
+        slot_of = (int *)malloc((size_t)t->n_items * sizeof(int));
+        for (int i = 0; i < n; ++i) slot_of[ids[i]] = i;
+    }
     for (int dim = 0; dim < t->dims; ++dim) {
         const kd_dim_order *od = sorted ? &order[dim] : NULL;
-        if (sorted)
+        if (sorted) {
             for (int i = 0; i < od->n_reg; ++i) {
                 los[i] = t->items[od->lo[i]].lower[dim];
                 ups[i] = t->items[od->up[i]].upper[dim];
             }
+            /* The candidates of the regular items in ascending order: both counts only grow, two pointers follow them (the
+             * comparisons are count_below's / count_above's).  Lower-bound candidates first, then upper-bound ones. */
+            for (int end = 0; end < 2; ++end) {
+                int a = 0, b = 0;       /* a = #{ups < x}, b = #{los <= y} */
+                for (int k = 0; k < od->n_reg; ++k) {
+                    const int id = end == 0 ? od->lo[k] : od->up[k];
+                    const double cand = end == 0 ? los[k] - 2 * EPSILON : ups[k] + 2 * EPSILON;
+                    const double x = cand - EPSILON, y = cand + EPSILON;
+                    while (a < od->n_reg && ups[a] < x) ++a;
+                    while (b < od->n_reg && !(los[b] > y)) ++b;
+                    left_of[4 * slot_of[id] + 2 * end] = a;
+                    left_of[4 * slot_of[id] + 2 * end + 1] = od->n_reg - b;
+                }
+            }
+        }
         for (int i = 0; i < n; ++i) {
             const ndt_kd_item *it = &t->items[ids[i]];
+            const int regular = it->lower[dim] <= it->upper[dim];
             for (int end = 0; end < 2; ++end) {
                 const double cand = end == 0 ? it->lower[dim] - 2 * EPSILON : it->upper[dim] + 2 * EPSILON;
                 int ok;
                 if (sorted) {
                     const double x = cand - EPSILON, y = cand + EPSILON;
-                    int left = count_below(ups, od->n_reg, x), right = count_above(los, od->n_reg, y);
+                    int left, right;
+                    if (regular) { left = left_of[4 * i + 2 * end]; right = left_of[4 * i + 2 * end + 1]; }
+                    else { left = count_below(ups, od->n_reg, x); right = count_above(los, od->n_reg, y); }
                     /* the inverted ones: descending by upper bound, so those not on the left come first */
                     int j = 0;
                     for (; j < od->n_inv && !(t->items[od->inv[j]].upper[dim] < x); ++j)
@@ -196,6 +223,8 @@ static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, cons
             }
         }
     }
+    free(left_of);
+    free(slot_of);
     free(los);
     free(ups);
     if (!found) {
