@@ -144,7 +144,10 @@ int ndt_flatten_scene_mt(scene *scn, ndt_flat_builder *fb, char *err, int err_le
     ndt_kd_tree kd;
     ndt_kd_init(&kd, dims);
     for (int i = 0; i < scn->num_objects; ++i) {
-        object_get_bounds(scn->object_ptrs[i]);
+        /* (ndt.c:1905 fits every top-level object.  A cluster's own sphere -- one search over the bounding points of all its
+         * members, 172 000 of them for the 8-D hypercube -- is never looked at again: the kd-tree takes its members one by
+         * one, object.c:633-681, and nothing else of this path reads it.  Not fitted.) */
+        if (ndt_object_type_id(scn->object_ptrs[i]) != NDT_TYPE_CLUSTER) object_get_bounds(scn->object_ptrs[i]);
         ndt_kd_add_object(&kd, scn->object_ptrs[i]);
     }
     ndt_kd_build(&kd);
