@@ -158,7 +158,7 @@ static kd_dim_order *child_order(const kd_dim_order *parent, int dims, const uns
 
 /* kd_tree_split_node, kd-tree.c:315-419.  order: NULL, or the node's items per dimension (above); side: scratch, one byte per
  * item of the tree */
-static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, const kd_dim_order *order, unsigned char *side)
+static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, const kd_dim_order *order, unsigned char *side, int *slot_of)
 {
     ndt_kd_node *node = (ndt_kd_node *)calloc(1, sizeof(ndt_kd_node));
     int found = 0, split_dim = -1;
@@ -167,13 +167,8 @@ static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, cons
     double *los = sorted ? (double *)malloc((size_t)n * sizeof(double)) : NULL, *ups = sorted ? (double *)malloc((size_t)n * sizeof(double)) : NULL;
     /* scores of the candidates of the regular items, by item (filled per dimension by two sweeps) */
     int *left_of = sorted ? (int *)malloc((size_t)4 * n * sizeof(int)) : NULL;     /* [4 * i + 0 .. 3] for ids[i]: left, right of its lower / upper candidate */
-    int *slot_of = NULL;
-    if (sorted) {
-        /* position of an item in ids[]: through the tree-sized scratch behind `side` would need another array; a node-sized
-         * map keyed by the order arrays is enough -- the sweeps write through it */
-        slot_of = (int *)malloc((size_t)t->n_items * sizeof(int));
-        for (int i = 0; i < n; ++i) slot_of[ids[i]] = i;
-    }
+    if (sorted)
+        for (int i = 0; i < n; ++i) slot_of[ids[i]] = i;       /* where an item stands in ids[] (tree-sized scratch, like `side`) */
     for (int dim = 0; dim < t->dims; ++dim) {
         const kd_dim_order *od = sorted ? &order[dim] : NULL;
         if (sorted) {
@@ -224,7 +219,6 @@ static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, cons
         }
     }
     free(left_of);
-    free(slot_of);
     free(los);
     free(ups);
     if (!found) {
@@ -250,8 +244,8 @@ static ndt_kd_node *split_node(const ndt_kd_tree *t, const int *ids, int n, cons
         /* the children's orders (before the recursion reuses `side`) */
         kd_dim_order *lo_order = (sorted && nl >= KD_SORTED_MIN) ? child_order(order, t->dims, side, 1, nl) : NULL;
         kd_dim_order *ro_order = (sorted && nr >= KD_SORTED_MIN) ? child_order(order, t->dims, side, 2, nr) : NULL;
-        node->left = split_node(t, l, nl, lo_order, side);
-        node->right = split_node(t, r, nr, ro_order, side);
+        node->left = split_node(t, l, nl, lo_order, side, slot_of);
+        node->right = split_node(t, r, nr, ro_order, side, slot_of);
         free_order(lo_order, t->dims);
         free_order(ro_order, t->dims);
     } else {
@@ -313,8 +307,10 @@ void ndt_kd_build(ndt_kd_tree *t)
             qsort_r(o->inv, (size_t)o->n_inv, sizeof(int), cmp_item_bound, &c);
         }
     }
-    t->root = split_node(t, finite, nf, order, side);
+    int *slot_of = (int *)malloc((size_t)(t->n_items > 0 ? t->n_items : 1) * sizeof(int));
+    t->root = split_node(t, finite, nf, order, side, slot_of);
     free_order(order, t->dims);
+    free(slot_of);
     free(side);
     free(finite);
 }
