@@ -347,8 +347,9 @@ int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double
  * Returns the number of boxed items (0: none), <0 on NDT_E_*. */
 int ndt_hip_item_boxes(const ndt_flat_scene *scene, double *frame, double *rows, uint8_t *has);
 
-/* The stream the context launches on (a hipStream_t), for callers that time with their own
- * events or order other work against it. */
+/* The stream the context launches on (a hipStream_t, created hipStreamNonBlocking: nothing the caller queues on the NULL
+ * stream or any other is ordered against it implicitly), for callers that time with their own events or order other work
+ * against it. */
 void *ndt_hip_stream(ndt_hip_ctx *ctx);
 int ndt_hip_synchronize(ndt_hip_ctx *ctx);
 

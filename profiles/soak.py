@@ -27,6 +27,7 @@ while time.time() < t_end:
         g = ctxs[scene]
         rows = h
         buf = torch.full((2 * h + 64, 2 * w, 4), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.current_stream().synchronize()       # torch fills on its stream, the renderer writes on its own
         st = g.render_device(buf.data_ptr(), w, h, depth, **kw)
         torch.cuda.synchronize()
         img = buf[:rows, :w].clone() if not kw.get("stereo") else buf.clone()
