@@ -12,7 +12,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 cases = [("c3_random4d", 64, 36, 4, {}), ("c3_random4d", 480, 270, 4, {}), ("c3_random4d", 960, 540, 4, {}),
          ("c3_random4d", 1920, 1080, 4, {}), ("c2_balls4d", 640, 360, 128, {}), ("zoo3d_mirror", 320, 240, 128, {}),
          ("c5_hypercube6d", 480, 270, 128, {}), ("c3_random4d", 240, 135, 4, {"aa": (20, 3)}),
-         ("st_zoo4d_sbs", 160, 90, 6, {"stereo": 1})]
+         ("st_zoo4d_sbs", 160, 90, 6, {"stereo": 1}), ("c5_hypercube8d", 480, 270, 128, {}), ("c5_hypercube7d", 320, 180, 128, {}),
+         ("ns_zoo4d_dof", 96, 54, 6, {"samples": 4}), ("al_zoo4d", 96, 54, 5, {"samples": 2}), ("zoo10d", 120, 72, 5, {}),
+         ("c3_random4d", 3840, 2160, 4, {})]
 ctxs = {}
 first = {}
 count = {}
