@@ -339,6 +339,10 @@ int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *
  * bit f of *possible is clear when face f can never be hit.  Returns the number of faces, 0 when the
  * hcube has no face boxes (no hull box, or more than 63 faces), <0 on NDT_E_*. */
 int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double *face_rows, uint64_t *possible);
+/* ... for an hcube of any number of faces (a 6-D one nests 472, a 10-D one 52 904: the device takes their boxes 63 at a time):
+ * face_rows: n_faces x dims x { centre, half extent }, possible: one byte per face.  Returns the number of faces; with
+ * cap_faces too small (or null pointers) only that -- call again with room.  0: the hcube gets no boxes, <0 on NDT_E_*. */
+int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *scene, int32_t object, int64_t cap_faces, double *face_rows, uint8_t *possible);
 
 /* Diagnostic, host only: the item boxes the library derives at upload for scenes of more than 256 items -- one orthonormal
  * frame for the scene (frame: dims x unit axis[dims]) and, for every top-level orthotope, the box in that frame of every

@@ -32,9 +32,23 @@ extern "C" int ndt_hip_hcube_face_boxes(const ndt_flat_scene *fs, int32_t object
     if (rc <= 0) return rc;
     std::vector<double> rows;
     HullFaces hf;
-    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0 || hf.n_faces > 63) return 0;
     memcpy(face_rows, hf.rows.data(), hf.rows.size() * sizeof(double));
-    *possible = hf.possible;
+    *possible = hf.possible[0];
+    return hf.n_faces;
+}
+
+extern "C" int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *fs, int32_t object, int64_t cap_faces, double *face_rows, uint8_t *possible)
+{
+    std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
+    const int rc = ndt_hip_hcube_hull_box(fs, object, hull.data());      // validates the arguments
+    if (rc <= 0) return rc;
+    std::vector<double> rows;
+    HullFaces hf;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    if (!face_rows || !possible || cap_faces < hf.n_faces) return hf.n_faces;        // (how many: call again with room for them)
+    memcpy(face_rows, hf.rows.data(), hf.rows.size() * sizeof(double));
+    for (int f = 0; f < hf.n_faces; ++f) possible[f] = (uint8_t)((hf.possible[(size_t)f / NDT_HULL_CHUNK] >> (f % NDT_HULL_CHUNK)) & 1ull);
     return hf.n_faces;
 }
 
@@ -171,7 +185,8 @@ static int kd_preorder(const ndt_flat_scene *fs, int node, int depth, std::vecto
 #define NDT_HULL_MARGIN 0.02
 #define NDT_HULL_DELTA 0.01485      /* sqrt(2e-4) * 1.05 */
 #define NDT_HULL_EPS 1.1e-4
-#define NDT_HULL_MAX_FACES 63       /* face boxes: one bit per face in a 64-bit word whose top bit stays clear (trace_kd) */
+#define NDT_HULL_CHUNK 63           /* face boxes: 63 faces a mask word -- one bit per face, the top bit stays clear (trace_kd) */
+#define NDT_HULL_MAX_FACES (1 << 22) /* ... and as many words as the hcube needs (a 10-D one nests 52 904 faces) */
 
 // cyclic Jacobi: a (m x m, symmetric, row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of w
 static void jacobi_eig(std::vector<double> &a, std::vector<double> &w, int m)
@@ -393,14 +408,15 @@ bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o
         // cannot produce a point face f's intersect() accepts (same argument, one face at a time), so the device
         // scans only the faces whose box the ray meets -- of the 2-D faces of a 4-D hcube, usually none or two.
         faces->rows.clear();
-        faces->possible = 0;
+        faces->possible.clear();
         faces->n_faces = 0;
-        if (o.n_obj <= NDT_HULL_MAX_FACES) {
+        if (o.n_obj >= 1 && o.n_obj <= NDT_HULL_MAX_FACES) {
             faces->n_faces = o.n_obj;
+            faces->possible.assign((size_t)(o.n_obj + NDT_HULL_CHUNK - 1) / NDT_HULL_CHUNK, 0ull);
             face_begin.push_back(n_pts);
             for (int k = 0; k < o.n_obj; ++k) {
                 const size_t p0 = face_begin[k], p1 = face_begin[k + 1];
-                if (p1 > p0) faces->possible |= 1ull << k;
+                if (p1 > p0) faces->possible[(size_t)k / NDT_HULL_CHUNK] |= 1ull << (k % NDT_HULL_CHUNK);
                 for (int a = 0; a < n; ++a) {
                     double lo = 1e300, hi = -1e300;
                     for (size_t i = p0; i < p1; ++i) {
@@ -744,9 +760,9 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
                 flags |= NDT_F_BOX;
                 for (double x : rows) b.push(x);
                 if (hf.n_faces > 0 && ctx->face_box) {
-                    // { possible-faces mask } + per face N x { centre, half extent }
+                    // { possible-faces masks, one word per 63 faces } + per face N x { centre, half extent }
                     flags |= NDT_F_FACEBOX;
-                    b.push_ints((int)(hf.possible & 0xffffffffull), (int)(hf.possible >> 32));
+                    for (unsigned long long w : hf.possible) b.push_ints((int)(w & 0xffffffffull), (int)(w >> 32));
                     for (double x : hf.rows) b.push(x);
                 }
             } else {

@@ -139,8 +139,9 @@ namespace ndt_impl {
 struct HullFaces {
     // per face of the hcube, in the hull box's frame: N x { centre coordinate, half extent } -- the face's own
     // box, same derivation and margin as the hull box; possible bit f clear = face f can never be hit
+    // (possible: one word per 63 faces, bit j of word c = face 63 c + j; the top bit of every word stays clear)
     std::vector<double> rows;
-    unsigned long long possible = 0;
+    std::vector<unsigned long long> possible;
     int n_faces = 0;
 };
 bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);

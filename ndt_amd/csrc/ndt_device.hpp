@@ -709,8 +709,11 @@ NDT_DEV bool slab_interval_holds(double lo, double hi)
 {
     return !(__builtin_fma(-fabs(lo), NDT_SLAB_GIVE, lo) > __builtin_fma(fabs(hi), NDT_SLAB_GIVE, hi));
 }
+// (more than 63 faces: the masks come 63 faces at a time -- `chunk` is where to start looking and, on return, the chunk of the
+// mask that came back: the first one from there on in which the ray meets a face's box)
+#define NDT_HULL_CHUNK 63
 template <int N>
-NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N])
+NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N], int &chunk)
 {
     double po[N], inv[N];       // u_k.o and 1/(u_k.v); 0 marks a ray parallel to slab k
     double t0 = 0.0, t1 = NDT_DBL_MAX;
@@ -745,34 +748,41 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
     if (!any || !ok) return 0;
     if (!face_boxes) return -1;
     const int fr = p + N * (N + 2);
-    unsigned long long live = 0ull;
-    for (int f = 0; f < nf; ++f) {
-        const int q = fr + 1 + f * 2 * N;
-        double f0 = 0.0, f1 = NDT_DBL_MAX;
-        bool fok = true;
-        bool fany = true;
+    const int n_chunks = (nf + NDT_HULL_CHUNK - 1) / NDT_HULL_CHUNK;
+    for (; chunk < n_chunks; ++chunk) {
+        const int f_begin = chunk * NDT_HULL_CHUNK, f_end = (f_begin + NDT_HULL_CHUNK < nf) ? f_begin + NDT_HULL_CHUNK : nf;
+        unsigned long long live = 0ull;
+        for (int f = f_begin; f < f_end; ++f) {
+            const int q = fr + n_chunks + f * 2 * N;
+            double f0 = 0.0, f1 = NDT_DBL_MAX;
+            bool fok = true;
+            bool fany = true;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (fany) {
-                const double a = po[k] - blob[q + 2 * k];
-                const double h = blob[q + 2 * k + 1];
-                if (inv[k] == 0.0) {
-                    if (fabs(a) > h) fok = false;
-                } else {
-                    const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
-                    const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
-                    if (lo > f0) f0 = lo;
-                    if (hi < f1) f1 = hi;
-                }
-                if ((k & 1) && k + 1 < N) {
-                    fok = fok && slab_interval_holds(f0, f1);
-                    fany = __ballot(fok) != 0ull;
+            for (int k = 0; k < N; ++k) {
+                if (fany) {
+                    const double a = po[k] - blob[q + 2 * k];
+                    const double h = blob[q + 2 * k + 1];
+                    if (inv[k] == 0.0) {
+                        if (fabs(a) > h) fok = false;
+                    } else {
+                        const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                        const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                        if (lo > f0) f0 = lo;
+                        if (hi < f1) f1 = hi;
+                    }
+                    if ((k & 1) && k + 1 < N) {
+                        fok = fok && slab_interval_holds(f0, f1);
+                        fany = __ballot(fok) != 0ull;
+                    }
                 }
             }
+            if (fany && fok && slab_interval_holds(f0, f1)) live |= 1ull << (f - f_begin);
         }
-        if (fany && fok && slab_interval_holds(f0, f1)) live |= 1ull << f;
+        live &= (unsigned long long)__double_as_longlong(blob[fr + chunk]);
+        // (the lanes of a wavefront may be on different hcubes or chunks: every lane leaves with ITS first non-empty chunk)
+        if (live != 0ull) return (long long)live;
     }
-    return (long long)(live & (unsigned long long)__double_as_longlong(blob[fr]));
+    return 0;
 }
 
 // ------------------------------------------------------------------ item boxes
@@ -1324,7 +1334,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     // nested (hcube) list
     bool in_sub = false;
     int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
-    long long sub_live = -1;                // faces still to scan, bit 0 = the one at sub_i (all ones: every face)
+    long long sub_live = -1;                // faces still to scan, bit 0 = the one at sub_i (all ones: every face; 0: sub_i
+                                            // stands at the start of a chunk of 63 faces whose boxes are yet to be looked at)
     double sub_min = -1;
 
     if (!has_ray) {
@@ -1563,6 +1574,29 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             bool scanning = true;
             while (scanning) {
                 NDT_OCC(1);
+                if (in_sub && sub_live == 0) {
+                    // The hcube's faces from the chunk sub_i stands on: hull box, then the boxes of 63 faces at a time until
+                    // the ray meets one (one call site for the first faces of an hcube and for its later chunks).  Nothing
+                    // met: the nested trace() is over -- for an hcube just entered, before it began (its result: no hit).
+                    const int oflags = blob_int(blob, sd.off_hdr + 2 * sub_owner, 0);
+                    const int first = blob_int(blob, sd.off_hdr + 2 * sub_owner + 1, 0);
+                    const bool fresh_hcube = sub_i == first;
+                    long long live = -1;
+                    int chunk = (sub_i - first) / NDT_HULL_CHUNK;
+                    if (oflags & NDT_F_BOX)
+                        live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * sub_owner, 1),
+                                             (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk);
+                    if (live == 0) {
+                        // (an hcube just entered: it never began -- no result to apply, the scan goes on in this very step)
+                        if (fresh_hcube) in_sub = false;
+                        else sub_i = sub_end;
+                        sub_live = -1;
+                    } else {
+                        const int skip = __ffsll(live) - 1;
+                        sub_i = first + ((live == -1) ? 0 : chunk * NDT_HULL_CHUNK) + skip;
+                        sub_live = live >> skip;
+                    }
+                }
                 if (in_sub && sub_i == sub_end) {
                     // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
                     // then the outer trace() applies its accept / break rules
@@ -1604,22 +1638,16 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             if (gate) {
                                 if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
                                     // composites only occur in outer lists (validated at upload)
+                                    // (which of its faces are scanned is found at the top of the scanning loop: sub_live == 0)
                                     const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
                                     const int nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
-                                    long long live = -1;
-                                    if (flags & NDT_F_BOX)
-                                        live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1),
-                                                             (flags & NDT_F_FACEBOX) != 0, nf, o, v);
-                                    if (live != 0) {
-                                        const int skip = __ffsll(live) - 1;
-                                        in_sub = true;
-                                        sub_owner = id;
-                                        sub_i = first + skip;
-                                        sub_end = first + nf;
-                                        sub_live = live >> skip;
-                                        sub_min = -1;
-                                        sub_prim = -1;
-                                    }
+                                    in_sub = true;
+                                    sub_owner = id;
+                                    sub_i = first;
+                                    sub_end = first + nf;
+                                    sub_live = 0;
+                                    sub_min = -1;
+                                    sub_prim = -1;
                                 } else {
                                     prim = id;
                                     scanning = false;
@@ -1658,7 +1686,12 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             // on to the next face whose box the ray meets (arithmetic shifts: all ones stays all ones)
                             const long long rest = sub_live >> 1;
                             if (rest == 0) {
-                                sub_i = sub_end;
+                                // this chunk of 63 faces is done: the next ones, if the hcube has more (sub_live is all ones
+                                // -- never 0 here -- when there are no face boxes)
+                                const int first = blob_int(blob, sd.off_hdr + 2 * sub_owner + 1, 0);
+                                const int next = first + ((sub_i - first) / NDT_HULL_CHUNK + 1) * NDT_HULL_CHUNK;
+                                if (next < sub_end) { sub_i = next; sub_live = 0; }
+                                else sub_i = sub_end;
                             } else {
                                 const int skip = __ffsll(rest) - 1;
                                 sub_i += 1 + skip;

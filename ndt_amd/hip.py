@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
-    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes",
+    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes", "ndt_hip_hcube_face_boxes_all",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
     "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
     "ndt_hip_item_boxes", "ndt_hip_render_rgba8_async", "ndt_hip_render_rgba8_wait",
@@ -71,6 +71,8 @@ def load_library():
     lib.ndt_hip_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.ndt_hip_hcube_hull_box.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_hcube_face_boxes_all.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_hcube_face_boxes_all.restype = C.c_int64
     lib.ndt_hip_render_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -115,20 +117,21 @@ def item_boxes(fs):
 
 
 def hcube_face_boxes(fs, obj):
-    """The boxes of the single faces of hcube `obj` in its hull box's frame (host only, no GPU):
-    (centre[F,N], half[F,N], possible[F] bool) or None when the hcube gets no face boxes."""
+    """The boxes of the single faces of hcube `obj` in its hull box's frame (host only, no GPU), for an hcube of any number of
+    faces: (centre[F,N], half[F,N], possible[F] bool) or None when the hcube gets no face boxes."""
     import numpy as np
     lib = load_library()
     n = fs.dims
-    rows = np.zeros((63, n, 2), dtype=np.float64)
-    possible = C.c_uint64(0)
-    rc = lib.ndt_hip_hcube_face_boxes(fs.byref(), int(obj), rows.ctypes.data, C.byref(possible))
-    if rc < 0:
-        raise NdtHipError(rc, (lib.ndt_hip_last_error() or b"").decode())
-    if rc == 0:
+    count = lib.ndt_hip_hcube_face_boxes_all(fs.byref(), int(obj), 0, None, None)
+    if count < 0:
+        raise NdtHipError(int(count), (lib.ndt_hip_last_error() or b"").decode())
+    if count == 0:
         return None
-    live = np.array([(possible.value >> f) & 1 for f in range(rc)], dtype=bool)
-    return rows[:rc, :, 0].copy(), rows[:rc, :, 1].copy(), live
+    rows = np.zeros((count, n, 2), dtype=np.float64)
+    possible = np.zeros(count, dtype=np.uint8)
+    rc = lib.ndt_hip_hcube_face_boxes_all(fs.byref(), int(obj), count, rows.ctypes.data, possible.ctypes.data)
+    assert rc == count
+    return rows[:, :, 0].copy(), rows[:, :, 1].copy(), possible.astype(bool)
 
 
 class NdtHip:

@@ -101,8 +101,7 @@ def test_every_oracle_hit_on_an_hcube_lies_inside_a_face_box(oracle, name):
     boxes = {h: hcube_hull_box(fs, h) for h in hs}
     faces = {h: hcube_face_boxes(fs, h) for h in hs}
     if all(f is None for f in faces.values()):
-        # more than 63 faces (a 5-D hcube of 2-faces has 80): hull box only
-        assert all(fs.objects[h]["n_obj"] > 63 or boxes[h] is None for h in hs)
+        assert all(boxes[h] is None for h in hs)      # (hcubes of any number of faces get them: 63 to a mask word on the device)
         pytest.skip("no hcube of this scene has face boxes")
     rays = aimed_rays(fs, boxes.get, seed=17)
     obj, hit, _ = oracle.trace(fs, rays)
