@@ -337,7 +337,7 @@ int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *
  * (same derivation, one face at a time): the nested trace() visits only the faces whose box the ray
  * meets.  face_rows receives n_faces x dims x { centre coordinate, half extent } (room for 63 faces);
  * bit f of *possible is clear when face f can never be hit.  Returns the number of faces, 0 when the
- * hcube has no face boxes (no hull box, or more than 63 faces), <0 on NDT_E_*. */
+ * hcube has no hull box, or more than 63 faces (then: ndt_hip_hcube_face_boxes_all), <0 on NDT_E_*. */
 int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double *face_rows, uint64_t *possible);
 /* ... for an hcube of any number of faces (a 6-D one nests 472, a 10-D one 52 904: the device takes their boxes 63 at a time):
  * face_rows: n_faces x dims x { centre, half extent }, possible: one byte per face.  Returns the number of faces; with

@@ -686,7 +686,7 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
 // The hull box test plus, for hcubes that carry them (NDT_F_FACEBOX), the same test against every face's own
 // box: returns 0 when the ray misses the hull box or every face box (skip the hcube), -1 when all faces are to be
 // scanned (no face boxes), otherwise the mask of the faces whose box the ray meets (bit f = nested primitive f,
-// at most 63 of them).  The projections u_k.o and 1/(u_k.v) of the hull test are shared by all the faces, so a
+// 63 of them to a call: `chunk`, below).  The projections u_k.o and 1/(u_k.v) of the hull test are shared by all the faces, so a
 // face costs N slab updates -- against ~20 orthotope intersections per hcube visit on the benchmark scene, of which
 // almost all missed.
 // Cost, as measured on the benchmark frame (profiles/r03_hull_probe.txt): 41 % of its rays pass the bounding-sphere gate of an
