@@ -61,7 +61,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ctx->device = device;
     {
         // the environment is read here, once: nothing on the render or upload path looks at it
-        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "multi_path", "sample_seed", "stream_fused", "shade_pair", "debug_levels",
+        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "shade_pair", "debug_levels",
                                              "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
         if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
@@ -147,6 +147,11 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
     else if (!strcmp(name, "gate_prepass")) ctx->gate_prepass = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "sample_seed")) ctx->sample_seed = value;
     else if (!strcmp(name, "leaf_scan")) ctx->leaf_scan = on;
+    else if (!strcmp(name, "coop")) ctx->coop = on;
+    else if (!strcmp(name, "coop_budget_us")) ctx->coop_budget_us = value < 0 ? 0 : value > 1000000 ? 1000000 : (int)value;
+    else if (!strcmp(name, "coop_max_live")) ctx->coop_max_live = value < 0 ? 0 : value > 64 ? 64 : (int)value;
+    else if (!strcmp(name, "coop_tail_only")) ctx->coop_tail_only = on;
+    else if (!strcmp(name, "coop_waves")) ctx->coop_waves = value < 1 ? 1 : value > 16 ? 16 : (int)value;
     else if (!strcmp(name, "leaf_scan_group")) ctx->leaf_scan_group = value < 1 ? 1 : value > 64 ? 64 : (int)value;
     else if (!strcmp(name, "leaf_history")) ctx->leaf_history = value < 0 ? 0 : value > 4 ? 4 : (int)value;
     else if (!strcmp(name, "multi_path")) {
@@ -266,6 +271,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.levels = nullptr;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
+    coop_setup(ctx, tj, nullptr);
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());

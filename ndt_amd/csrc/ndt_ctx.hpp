@@ -95,6 +95,16 @@ struct ndt_hip_ctx {
     bool item_boxes = true;         // global-memory tier: orthotopes carry a box in one scene-wide frame (ndt_blob.hip:scene_item_boxes)
     int leaf_scan_group = 64;       // ... when at least this many lanes share the leaf
     bool leaf_scan = true;          // global-memory tier: lanes on the same leaf stage its items through LDS (ndt_device.hpp:cls_scan)
+    // item-set tier: a batch of the trace kernel that is over coop_budget_us with at most coop_max_live rays left gives them up;
+    // they are traced one per wavefront by the wavefronts that have run out of batches (ndt_device.hpp:coop_trace).
+    // OFF by default: bit-identical answers (tests/test_gpu_parity.py), but measured slower on every setting tried -- a ray costs a
+    // wavefront 9-13 us that way, the slow batches of a launch turn out to be WIDE (dozens of rays alive until late, in step),
+    // and a launch has thousands of them, not a handful (profiles/experiments/r04_coop_stragglers.md)
+    bool coop = false;
+    int coop_budget_us = 25, coop_max_live = 8;
+    bool coop_tail_only = true;     // ... and only once the batch's queue shard has run dry (the launch is in its tail)
+    int coop_waves = 4;             // wavefronts of a workgroup that stay on as consumers
+    unsigned int coop_tag = 0;      // serial number of the last trace launch that had a straggler ring
     int leaf_history = 4;           // global-memory tier: visited = {leaf, cut} pairs per ray (VisitMask<0>); 0: the slab only; 1 .. 3: fewer pairs (tests)
     int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;
@@ -151,6 +161,7 @@ int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs);
 // ndt_frame.hip
 void free_workspace(ndt_hip_ctx *ctx);
 int ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap);
+void coop_setup(ndt_hip_ctx *ctx, TraceJob &tj, unsigned int *log);
 int render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rgba, ndt_render_stats &st, void *d_depth = nullptr);
 void launch_fill_black(hipStream_t s, double *rgba, long long n_pixels);
 void add_stats(ndt_render_stats &acc, const ndt_render_stats &st);

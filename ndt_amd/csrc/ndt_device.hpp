@@ -1261,13 +1261,26 @@ struct KdStackLds {
 // coherent rays scan the same leaf in the same order: 80-90 % of the intersections of the 6-D .. 8-D scenes -- its number
 // is made a scalar, so that its records are read with scalar loads into scalar registers: no per-lane addresses, no
 // vector registers for data that is the same in all lanes (in 8-D a vector is 16 of them).  Same arithmetic.
+// When a wavefront may give up on the last rays of a batch (item-set tier, per-bounce trace kernel): its few slowest rays
+// keep 64 lanes for tens of microseconds each; given up, they are queued and traced again from the start by coop_trace
+// (below), one ray per wavefront, on the wavefronts that have run out of batches.  tail == nullptr: never.
+struct TraceAbandon {
+    const int *tail;                // the straggler queue's tail: nothing is given up once it has passed tail_limit
+    unsigned long long deadline;    // wall_clock64() after which the batch is over its budget
+    int max_live;                   // ... and at most this many of its rays are still being traced
+    int tail_limit;
+    const int *dry_word;            // nullptr, or: only once this word has reached dry_at (the wavefront's queue shard has run
+    int dry_at;                     // dry: the launch is in its tail, and wavefronts without a batch are waiting for stragglers)
+};
+
 template <int N, int MW, bool LSTACK = false, bool UNI = false>
 NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &mask, const double (&o)[N],
                       const double (&v)[N], double dist_limit, int &out_obj, int &out_prim
 #ifdef NDT_PHASE_TIMING
                       , unsigned long long (&ph)[8], unsigned int (&cnt)[8], unsigned int (&occ)[8]
 #endif
-                      , KdStackLds ls = KdStackLds{}, ClsLds cl = ClsLds{}, const bool has_ray = true, double *box_slot = nullptr)
+                      , KdStackLds ls = KdStackLds{}, ClsLds cl = ClsLds{}, const bool has_ray = true, double *box_slot = nullptr,
+                      const TraceAbandon ab = TraceAbandon{}, bool *gave_up = nullptr)
 {
 #ifdef NDT_PHASE_TIMING
     unsigned long long ph_last = __builtin_readcyclecounter();
@@ -1360,6 +1373,16 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     // of exec-mask bookkeeping loops it builds for early-continue code, which cost about as many
     // scalar instructions as the arithmetic itself.
     while (true) {
+        if (MW == 1 && !UNI && ab.tail) {
+            // the rays still here (every active lane has one) are the batch's slowest: over the budget, and few enough
+            // that a wavefront each serves them better?  (wave-uniform: active lanes, a scalar clock, one address)
+            if (__popcll(__ballot(true)) <= ab.max_live && wall_clock64() > ab.deadline &&
+                (!ab.dry_word || __builtin_amdgcn_readfirstlane(__hip_atomic_load(ab.dry_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= ab.dry_at) &&
+                __builtin_amdgcn_readfirstlane(__hip_atomic_load(ab.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ab.tail_limit) {
+                *gave_up = true;
+                break;
+            }
+        }
         // ------------------------------------------------------------ phase T
         if (!have_list && !done && root_pending) {
             root_pending = false;
@@ -1789,4 +1812,312 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             out_prim = l_prim;
         }
     }
+}
+
+// ------------------------------------------------------------------ cooperative trace: ONE ray, a whole wavefront
+//
+// The slowest rays of a frame (a ray along the edge of an hcube: ~55 tree steps, ~50 gates, ~40 intersections, every one a
+// dependent chain in one lane) set the tail of every trace launch and the latency floor of every pass.  What such a ray
+// computes is almost all independent of the order it is computed in:
+//   * intersect(item, ray) -- for an hcube the nested trace() over its faces, which starts from nothing (hcube.c:241) --
+//     and the part of the bounding-sphere gate that does not involve min_dist (bounding.c:60-85) are functions of the ray
+//     and the item alone: lane i computes them for item i, all <= 64 items of the scene in one round;
+//   * what depends on the order -- trace()'s running min_dist (the gate's first test, bounding.c:44-53; the accept rule
+//     object.c:722; the dist_limit break :730), the visit marks, `*t_ptr` across leaves (kd-tree.c:506) and kd_node_intersect's
+//     walk itself (kd-tree.c:482-568) -- is then replayed on those results: scalars only, the same comparisons on the same
+//     operands in the same order, so the same decisions and the same answer (object, primitive), bit for bit.
+// The replay needs only the items whose intersect() returned a hit: an item that is gated out or missed changes nothing
+// whenever the scan reaches it, except its own visit mark -- so every such item counts as visited from the start, leaves
+// and whole subtrees without an unvisited hit are not entered (the rule trace_kd's item sets already use: `below`), and a
+// ray that met forty bounding spheres and three objects walks towards three objects.
+//
+// Called with all 64 lanes active and the same ray in every lane.  Item-set scenes only (sd.mask_words == 1, sets in the
+// blob: sd.off_nset, sd.inf_bits).
+
+NDT_DEV double lane_get(double x, int l)        // x of lane l (l: the same in every lane)
+{
+    const int ls = __builtin_amdgcn_readfirstlane(l);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), ls), hi = __builtin_amdgcn_readlane(__double2hiint(x), ls);
+    return __hiloint2double(hi, lo);
+}
+// x with lane l's value replaced by val (val, l: the same in every lane)
+NDT_DEV int lane_put(int x, int val, int l) { return ((int)__lane_id() == l) ? val : x; }
+NDT_DEV double lane_put(double x, double val, int l) { return ((int)__lane_id() == l) ? val : x; }
+// a condition that is the same in every lane, as a scalar branch
+#define NDT_UNI(c) (__ballot(c) != 0ull)
+
+template <int N>
+NDT_DEV void coop_trace(const double *blob, const SceneDesc &sd, const double (&o)[N], const double (&v)[N], const double dist_limit,
+                        int &out_obj, int &out_prim)
+{
+    const int lane = __lane_id();
+    // ---- 1. item `lane` against the ray: gate without min_dist, intersect() (an hcube: its nested trace())
+    bool ok = false;                // intersect() was reached and returned a hit
+    double dist = 0.0;              // |o - hit|, object.c:721
+    double oc2 = -1.0, rad = 0.0;   // the gate's |o - c|^2 and radius (an item without a gate: never rejected)
+    int prim = -1;                  // the primitive that was hit (an hcube: the face its trace() accepted)
+    {
+        const bool has = lane < sd.n_items;
+        const int id = has ? lane : 0;
+        const int flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
+        bool pass = has;
+        if (has && (flags & NDT_F_GATE)) {
+            // vect_bounding_sphere_intersect without its min_dist test (bsphere_gate with min_dist < 0: same operations)
+            const int b = sd.off_bs + id * (N + 2);
+            double c[N], oc[N];
+            blob_vec<N>(blob, b, c);
+            v_sub<N>(o, c, oc);
+            const double oc_len2 = v_dot<N>(oc, oc);
+            const double voc = v_dot<N>(v, oc);
+            const double voc2 = voc * voc;
+            const double desc = voc2 - oc_len2 + blob[b + N + 1];
+            if (desc < 0.0 || (voc > 0.0 && voc2 > desc)) pass = false;
+            oc2 = oc_len2;
+            rad = blob[b + N];
+        }
+        const bool cube = pass && (flags & NDT_F_TYPE_MASK) == T_HCUBE;
+        bool single = pass && !cube;
+        // an hcube's faces: hull box, then face boxes 63 at a time, as trace_kd's nested scan takes them
+        int f_first = 0, nf = 0, pbox = 0;
+        if (cube) {
+            f_first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
+            nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
+            pbox = sd.off_params + blob_int(blob, sd.off_hdr + 2 * id, 1);
+        }
+        bool cube_open = cube && nf > 0, all_faces = false;
+        long long live = 0;         // faces of chunk `chunk` still to look at (bit j = face 63 chunk + j)
+        int chunk = 0, f_next = 0;
+        double sub_min = -1;
+        int sub_prim = -1;
+        while (true) {
+            int p = -1;
+            bool nested = false;
+            if (single) {
+                p = id;
+                single = false;
+            } else {
+                while (cube_open && p < 0) {
+                    if (live == 0 && !all_faces) {
+                        long long lv = -1;
+                        int ch = chunk;
+                        if (flags & NDT_F_BOX) lv = hull_faces<N>(blob, pbox, (flags & NDT_F_FACEBOX) != 0, nf, o, v, ch);
+                        if (lv == 0) {
+                            cube_open = false;          // the ray misses the hull box, or every face box from `chunk` on
+                        } else if (lv == -1) {
+                            all_faces = true;           // no face boxes: every face, in order
+                            f_next = f_first;
+                        } else {
+                            live = lv;
+                            chunk = ch;
+                        }
+                    }
+                    if (cube_open) {
+                        int f;
+                        if (all_faces) {
+                            f = f_next++;
+                            if (f_next == f_first + nf) cube_open = false;
+                        } else {
+                            f = f_first + chunk * NDT_HULL_CHUNK + (__ffsll(live) - 1);
+                            live &= live - 1;
+                            if (live == 0) {
+                                ++chunk;
+                                if (chunk * NDT_HULL_CHUNK >= nf) cube_open = false;
+                            }
+                        }
+                        int fid, fflags;
+                        blob_ref(blob, sd.off_child + f, fid, fflags);
+                        bool gate = true;
+                        if (fflags & NDT_F_GATE) gate = bsphere_gate<N>(blob, sd, fid, o, v, sub_min);     // object.c:618-624
+                        if (gate) {
+                            p = fid;
+                            nested = true;
+                        }
+                    }
+                }
+            }
+            if (__ballot(p >= 0) == 0ull) break;
+            if (p >= 0) {
+                double res[N], nrm[N];
+                if (isect<N, false>(blob, sd, p, o, v, res, nrm)) {
+                    const double d = v_dist<N>(o, res);                                     // object.c:721
+                    if (nested) {
+                        // the hcube's own trace(): dist_limit -1, no mask (hcube.c:241)
+                        if (d > NDT_EPS && (d + NDT_EPS < sub_min || sub_min < 0)) {
+                            sub_min = d;
+                            sub_prim = p;
+                        }
+                    } else {
+                        ok = true;
+                        dist = d;
+                        prim = p;
+                    }
+                }
+            }
+        }
+        if (cube) {
+            ok = sub_min >= 0;      // hcube.intersect's return (hcube.c:241-248); the distance is the accepted face's
+            dist = sub_min;
+            prim = sub_prim;
+        }
+    }
+    const unsigned long long okmask = __ballot(ok);
+
+    // ---- 2. the replay: trace() and kd_node_intersect over those results
+    unsigned long long visited = ~okmask;
+    // trace() (object.c:692-747) over the items of `cand`, ascending
+    auto scan = [&](unsigned long long cand, const bool masked, double &min_dist, int &best) {
+        min_dist = -1;
+        best = -1;
+        while (NDT_UNI(cand != 0ull)) {
+            const int i = __ffsll((long long)cand) - 1;
+            const unsigned long long bit = 1ull << i;
+            cand ^= bit;
+            if (masked) visited |= bit;                                                     // object.c:713
+            const double d = lane_get(dist, i);
+            bool pass = true;
+            if (NDT_UNI(min_dist > 0)) {                                                    // bounding.c:44-53
+                const double min_dist_r = min_dist + lane_get(rad, i);
+                if (lane_get(oc2, i) > min_dist_r * min_dist_r) pass = false;
+            }
+            if (NDT_UNI(pass)) {
+                if (d > NDT_EPS && (d + NDT_EPS < min_dist || min_dist < 0)) {              // object.c:722
+                    min_dist = d;
+                    best = i;
+                }
+                if (dist_limit == 0.0 || d < dist_limit) cand = 0ull;                       // object.c:730
+            }
+        }
+    };
+    // kd_tree_intersect, kd-tree.c:570-625
+    double t_inf = NDT_DBL_MAX;
+    bool ret_inf = false;
+    int inf_best = -1;
+    if (sd.n_inf > 0) {
+        double md;
+        scan(sd.inf_bits & okmask, false, md, inf_best);
+        ret_inf = md >= 0;
+        if (md > NDT_EPS) t_inf = md;                                                       // object.c:736
+    }
+    double lt = NDT_DBL_MAX;
+    bool lret = false;
+    int l_best = -1;
+    // aabb_intersect on the root box, kd-tree.c:84-127 (as in trace_kd)
+    double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
+    bool box = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (box) {
+            const double v_i = v[i], o_i = o[i];
+            if (!(fabs(v_i) < NDT_EPS2)) {
+                double tl_i = (blob[sd.off_bb + i] - o_i) / v_i;
+                double tu_i = (blob[sd.off_bb + N + i] - o_i) / v_i;
+                if (tl_i > tu_i) {
+                    const double tmp = tl_i;
+                    tl_i = tu_i;
+                    tu_i = tmp;
+                }
+                if (tl_i > tl) tl = tl_i;
+                if (tu_i < tu) tu = tu_i;
+                if (tu < -NDT_EPS) box = false;
+            }
+        }
+    }
+    if (box) {
+        tl -= NDT_EPS;
+        tu += NDT_EPS;
+        box = (tu >= -NDT_EPS) && (tl <= tu);
+    }
+    if (NDT_UNI(box && sd.n_kd_nodes > 0)) {
+        double v_inv[N];            // kd-tree.c:576-590
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double v_i = v[i];
+            if (v_i < NDT_EPS2 && v_i >= 0.0) v_inv[i] = NDT_INV_EPS2;
+            else if (v_i > -NDT_EPS2 && v_i <= 0.0) v_inv[i] = -NDT_INV_EPS2;
+            else v_inv[i] = 1.0 / v_i;
+        }
+        // kd_node_intersect on an explicit stack (trace_kd's phase T); entry d of the stack lives in lane d
+        int st_node = 0;
+        double st_a = 0.0, st_tu = 0.0;
+        int sp = 0, node = 0;
+        double ntl = tl, ntu = tu;
+        bool have_node = true;
+        while (true) {
+            bool visit = have_node;
+            if (NDT_UNI(!have_node)) {
+                if (NDT_UNI(sp == 0)) break;
+                --sp;
+                const int nf = __builtin_amdgcn_readlane(st_node, __builtin_amdgcn_readfirstlane(sp));
+                const double a = lane_get(st_a, sp);
+                ntu = lane_get(st_tu, sp);
+                node = nf & ~NDT_STACK_FLAG;
+                ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
+                visit = lt > a;                                                             // `*t_ptr > tp`, kd-tree.c:552
+            }
+            have_node = false;
+            if (NDT_UNI(visit && !(ntu < 0.0))) {                                           // kd-tree.c:490
+                const int nd = __builtin_amdgcn_readfirstlane(node);
+                const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * nd);
+                const unsigned long long below = (unsigned long long)__double_as_longlong(blob[sd.off_nset + nd]) & ~visited;
+                const long long w0 = __double_as_longlong(rec.x);
+                const int dim = __builtin_amdgcn_readfirstlane((int)(w0 & 0xffffffffll));
+                if (NDT_UNI(below == 0ull)) {
+                    // nothing below this node can change the ray's state any more
+                } else if (dim < 0) {
+                    // a leaf: trace() over its unvisited items (kd-tree.c:497-519)
+                    double md;
+                    int bi;
+                    scan(below, true, md, bi);
+                    if (NDT_UNI(md >= 0)) {
+                        lret = true;
+                        if (md < lt) {                                                      // `ret && t < *t_ptr`, kd-tree.c:506
+                            lt = md;
+                            l_best = bi;
+                        }
+                    }
+                } else {
+                    const double boundary = rec.y;
+                    const double v_inv_i = v_pick<N>(v_inv, dim);
+                    const double o_i = v_pick<N>(o, dim);
+                    const bool swap = v_inv_i < NDT_EPS2;
+                    const int left = nd + 1, right = (int)(w0 >> 32);
+                    const int near = swap ? right : left, far = swap ? left : right;
+                    if (NDT_UNI(-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2)) {
+                        const double tp = (boundary - o_i) * v_inv_i;
+                        const bool alive = lt > ntl;
+                        // kd-tree.c:541-554
+                        if (NDT_UNI(ntu < tp - NDT_EPS && alive)) {
+                            node = near; have_node = true;
+                        } else if (NDT_UNI(ntl > tp + NDT_EPS && alive)) {
+                            node = far; have_node = true;
+                        } else {
+                            if (NDT_UNI(lt > tp)) {
+                                st_node = lane_put(st_node, far, sp);
+                                st_a = lane_put(st_a, tp, sp);
+                                st_tu = lane_put(st_tu, ntu, sp);
+                                ++sp;
+                            }
+                            if (alive) { node = near; ntu = tp + NDT_EPS; have_node = true; }
+                        }
+                    } else {
+                        // plane parallel to the ray (kd-tree.c:555-565): unreachable, as in trace_kd
+                        if (NDT_UNI(o_i > boundary - NDT_EPS)) {
+                            st_node = lane_put(st_node, far | NDT_STACK_FLAG, sp);
+                            st_a = lane_put(st_a, ntl, sp);
+                            st_tu = lane_put(st_tu, ntu, sp);
+                            ++sp;
+                        }
+                        if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
+                    }
+                }
+            }
+        }
+    }
+    int best = inf_best;
+    if (lret) {
+        if (!ret_inf || (lt > NDT_EPS && lt + NDT_EPS < t_inf)) best = l_best;              // kd-tree.c:612
+    }
+    best = __builtin_amdgcn_readfirstlane(best);
+    out_obj = best;
+    out_prim = best >= 0 ? __builtin_amdgcn_readlane(prim, best) : -1;
 }

@@ -40,14 +40,31 @@ template <typename T> static int ws_alloc(ndt_hip_ctx *ctx, T **p, size_t count,
     return NDT_OK;
 }
 
+// The cooperative stragglers of one trace launch (TraceJob::coop_ring; ndt_device.hpp:coop_trace): scenes with item sets only.
+void ndt_impl::coop_setup(ndt_hip_ctx *ctx, TraceJob &tj, unsigned int *log)
+{
+    tj.coop_ring = nullptr;
+    if (!ctx->coop || ctx->tier != 0 || ctx->sd.mask_words != 1 || !ctx->ws.coop_ring) return;
+    tj.coop_ring = ctx->ws.coop_ring;
+    if (++ctx->coop_tag == 0u) ++ctx->coop_tag;         // (0 is what a cleared ring holds)
+    tj.coop_tag = ctx->coop_tag;
+    tj.coop_limit = NDT_COOP_RING_LIMIT;
+    tj.coop_budget = ctx->coop_budget_us * 100;         // 100 MHz ticks
+    tj.coop_max_live = ctx->coop_max_live;
+    tj.coop_tail_only = ctx->coop_tail_only ? 1 : 0;
+    tj.coop_waves = ctx->coop_waves;
+    tj.coop_log = log;
+}
+
 int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap)
 {
     Workspace &ws = ctx->ws;
     const bool need_slab = ctx->tier == 1;
     const long long slab_lanes = 2048LL * NDT_TRACE_BLOCK;
     const long long slab_words = need_slab ? slab_lanes * ctx->sd.mask_words : 0;
+    const bool need_ring = ctx->tier == 0 && ctx->sd.mask_words == 1;
     if (ws.cap >= cap && ws.sh_cap >= sh_cap && ctx->ws_dims == ctx->dims && ctx->ws_slab_words >= slab_words &&
-        ctx->ws_nseg >= ctx->n_shadow_lights)
+        ctx->ws_nseg >= ctx->n_shadow_lights && (ws.coop_ring != nullptr || !need_ring))
         return NDT_OK;
     if (cap < ws.cap) cap = ws.cap;
     if (sh_cap < ws.sh_cap) sh_cap = ws.sh_cap;
@@ -91,6 +108,12 @@ int ndt_impl::ensure_workspace(ndt_hip_ctx *ctx, long long cap, long long sh_cap
     if ((rc = ws_alloc(ctx, &ws.exit_log, (size_t)NDT_EXIT_LOG_LAUNCHES * NDT_EXIT_LOG_WORDS))) return give_up(rc);
     if (ctx->shade_probe >= 0 && (rc = ws_alloc(ctx, &ws.shade_log, (size_t)2 * NDT_SHADE_LOG_WAVES))) return give_up(rc);
     if ((rc = ws_alloc(ctx, &ws.levels, NDT_MAX_LEVELS + 1))) return give_up(rc);
+    if (ctx->tier == 0 && ctx->sd.mask_words == 1) {
+        // the straggler ring of the trace launches (TraceJob::coop_ring): cleared once -- an entry counts when it carries its launch's tag
+        if ((rc = ws_alloc(ctx, &ws.coop_ring, (size_t)NDT_COOP_RING_ENTRIES))) return give_up(rc);
+        if (hipMemsetAsync(ws.coop_ring, 0, (size_t)NDT_COOP_RING_ENTRIES * sizeof(unsigned long long), ctx->stream) != hipSuccess)
+            return give_up(fail(NDT_E_DEVICE, "clearing the straggler ring"));
+    }
     ws.mask_slab_lanes = slab_lanes;
     if (need_slab) {
         if ((rc = ws_alloc(ctx, &ws.mask_slab, (size_t)slab_words))) return give_up(rc);
@@ -631,6 +654,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             const bool exit_probe = ctx->exit_probe;
             tj.exit_log = (exit_probe && prof && launches < NDT_EXIT_LOG_LAUNCHES) ? ws.exit_log + (size_t)launches * NDT_EXIT_LOG_WORDS : nullptr;
+            coop_setup(ctx, tj, tj.exit_log ? reinterpret_cast<unsigned int *>(ws.dbg + 100 + 2 * launches) : nullptr);
             if (prof) {
                 hipEvent_t a = get_event(ctx, ev_n++), b2 = get_event(ctx, ev_n++);
                 kt->trace(s, ctx->d_blob, sd_pass, ws, tj, ctx->tier, ctx->sd.mask_words, a, b2);
@@ -904,26 +928,28 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                             const unsigned int *q = log.data() + (size_t)l * NDT_EXIT_LOG_WORDS;
                             unsigned int t0 = 0;
                             int n_w = 0;
-                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
-                                if (q[4 * w + 2]) {
-                                    if (!n_w || (int)(q[4 * w] - t0) < 0) t0 = q[4 * w];
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 8; ++w)
+                                if (q[8 * w + 2]) {
+                                    if (!n_w || (int)(q[8 * w] - t0) < 0) t0 = q[8 * w];
                                     ++n_w;
                                 }
                             int hist[64] = { 0 };
-                            double first = 1e30, last = 0, last_batch = 0, start_spread = 0;
+                            double first = 1e30, last = 0, last_batch = 0, start_spread = 0, last_exit = 0;
                             int simd_of_wave[16][4] = { { 0 } };        // workgroup wavefront w -> SIMD it ran on
                             int wpw = 12;                               // wavefronts per workgroup of this launch (logged by the kernel)
-                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 4; ++w)
-                                if (q[4 * w + 2]) {
-                                    const double st_us = (q[4 * w] - t0) / 100.0, ex_us = (q[4 * w + 2] - t0) / 100.0;
-                                    wpw = (int)(q[4 * w + 3] >> 24) > 0 && (q[4 * w + 3] >> 24) <= 16 ? (int)(q[4 * w + 3] >> 24) : wpw;
-                                    ++simd_of_wave[w % wpw][(q[4 * w + 3] >> 4) & 3];
+                            for (int w = 0; w < NDT_EXIT_LOG_WORDS / 8; ++w)
+                                if (q[8 * w + 2]) {
+                                    // "out of work" = out of batches (a consumer of the straggler ring exits when the launch closes)
+                                    const double st_us = (q[8 * w] - t0) / 100.0, ex_us = (q[8 * w + 4] - t0) / 100.0;
+                                    wpw = (int)(q[8 * w + 3] >> 24) > 0 && (q[8 * w + 3] >> 24) <= 16 ? (int)(q[8 * w + 3] >> 24) : wpw;
+                                    ++simd_of_wave[w % wpw][(q[8 * w + 3] >> 4) & 3];
                                     if (st_us > start_spread) start_spread = st_us;
                                     if (ex_us < first) first = ex_us;
                                     if (ex_us > last) {
                                         last = ex_us;
-                                        last_batch = (q[4 * w + 2] - q[4 * w + 1]) / 100.0;
+                                        last_batch = (q[8 * w + 4] - q[8 * w + 1]) / 100.0;
                                     }
+                                    if ((q[8 * w + 2] - t0) / 100.0 > last_exit) last_exit = (q[8 * w + 2] - t0) / 100.0;
                                     const int bin = (int)(ex_us / 16.0);
                                     ++hist[bin > 63 ? 63 : bin];
                                 }
@@ -945,6 +971,12 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                             }
                             fprintf(stderr, "ndt_hip: trace launch %d: %d wavefronts start within %.1f us; first out of work at %.1f us, last at %.1f us (its last batch: %.1f us); exits per 16 us:%s\n",
                                     l, n_w, start_spread, first, last, last_batch, line.c_str());
+                            {
+                                const unsigned int *cl = reinterpret_cast<const unsigned int *>(d + 100 + 2 * l);
+                                if (cl[0] || cl[1])
+                                    fprintf(stderr, "ndt_hip:    stragglers: %u rays given up, %u traced cooperatively (%.1f us each); the last wavefront left at %.1f us\n",
+                                            cl[0], cl[1], cl[1] ? cl[2] / 100.0 / cl[1] : 0.0, last_exit);
+                            }
                         }
                 }
                 if (d[4]) {

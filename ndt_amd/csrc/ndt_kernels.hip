@@ -351,6 +351,9 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         }
     }
     const int lane = __lane_id();
+    // cooperative stragglers (TraceJob::coop_ring): the item-set tier only
+    constexpr bool COOP = (MW == 1) && LDS;
+    const bool coop_on = COOP && job.coop_ring != nullptr;
     // NDT_HIP_EXIT_PROBE: when does every wavefront start, start its last batch, and run out of work
     const unsigned int probe_start = job.exit_log ? (unsigned int)wall_clock64() : 0u;
     unsigned int probe_batch = probe_start;
@@ -443,6 +446,18 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         }
         if (b < 0) break;
         if (job.exit_log) probe_batch = (unsigned int)wall_clock64();
+        TraceAbandon ab{};
+        if (COOP && coop_on) {
+            ab.tail = job.queue + NDT_COOP_TAIL;
+            ab.deadline = wall_clock64() + (unsigned long long)job.coop_budget;
+            ab.max_live = job.coop_max_live;
+            ab.tail_limit = job.coop_limit;
+            if (job.coop_tail_only) {
+                // the shard this batch came from: dry when its head has passed its last batch
+                ab.dry_word = job.queue + cur * NDT_QUEUE_STRIDE;
+                ab.dry_at = (int)((n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS);
+            }
+        }
         long long g;
         bool live;
         const bool in_seg = b >= dense_batches;         // wave-uniform
@@ -464,7 +479,8 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         // A lane without a ray.  The LDS tiers leave it out of the batch; in the global-memory tier it stays with the
         // wavefront as a helper of the coherent leaf scan (ndt_device.hpp:cls_scan: all 64 lanes fetch), with a ray that is
         // finished before it starts.
-        if (!live && !(MW == 0)) continue;
+        bool gave_up = false;
+        if (live || MW == 0) {
         const TracePart &part = in_seg ? job.seg : job.dense;
         double o[N], v[N];
 #ifdef NDT_TRACE_SKIP_KNOB
@@ -531,24 +547,117 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             prim = -1;
         } else
 #endif
-        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, kstack, cls, live, box_slot);
+        trace_kd<N, MW, LSTACK, MW == 0>(blob, sd, mask, o, v, lim, obj, prim, kstack, cls, live, box_slot, ab, &gave_up);
 #endif
 #ifdef NDT_TRACE_SKIP_KNOB
-        if (job.skip_trace == 2 && obj == -1) continue;
+        if (job.skip_trace == 2 && obj == -1) live = false;
 #endif
-        if (live) {
+        if (live && !gave_up) {
             part.out_obj[g] = obj;
             part.out_prim[g] = prim;
+        }
+        }
+        if (COOP && coop_on) {
+            // the rays this batch gave up: into the straggler ring, one reservation per wavefront
+            const unsigned long long gv = __ballot(live && gave_up);
+            if (gv != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(job.queue + NDT_COOP_TAIL, __popcll(gv));
+                base = __shfl(base, 0, 64);
+                if (live && gave_up) {
+                    const unsigned int payload = (unsigned int)g | (in_seg ? 0x80000000u : 0u);
+                    __hip_atomic_store(job.coop_ring + base + __popcll(gv & ((1ull << lane) - 1ull)),
+                                       ((unsigned long long)job.coop_tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (job.coop_log && lane == 0) atomicAdd(job.coop_log, (unsigned int)__popcll(gv));
+            }
+        }
+    }
+    const unsigned int probe_left = job.exit_log ? (unsigned int)wall_clock64() : 0u;
+    if (COOP && coop_on) {
+        // ---- this wavefront has no batch left.  It says so; the LAST one of the launch to say so closes the straggler ring:
+        // every ray that will ever be given up has been by then (a wavefront's pushes come before its own leaving), and each
+        // consumer holds exactly one ticket beyond the ring's final tail -- a closing entry goes into each of those slots.
+        const int waves_per_block = blockDim.x >> 6;
+        const int consumers_per_block = waves_per_block < job.coop_waves ? waves_per_block : job.coop_waves;
+        const int n_consumers = gridDim.x * consumers_per_block;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ring entries above are out
+        int closer = 0;
+        if (lane == 0) {
+            const int grp = blockIdx.x % NDT_COOP_GROUPS;
+            const int grp_blocks = ((int)gridDim.x - grp + NDT_COOP_GROUPS - 1) / NDT_COOP_GROUPS;
+            const int old = atomicAdd(job.queue + NDT_COOP_LEFT + grp * NDT_QUEUE_STRIDE, 1);
+            if (old + 1 == grp_blocks * waves_per_block) {
+                const int n_groups = (int)gridDim.x < NDT_COOP_GROUPS ? (int)gridDim.x : NDT_COOP_GROUPS;
+                closer = atomicAdd(job.queue + NDT_COOP_GROUPS_DONE, 1) + 1 == n_groups;
+            }
+        }
+        closer = __shfl(closer, 0, 64);
+        if (closer) {
+            int tail = 0;
+            if (lane == 0) tail = __hip_atomic_load(job.queue + NDT_COOP_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail = __shfl(tail, 0, 64);
+            for (int j = lane; j < n_consumers; j += 64)
+                __hip_atomic_store(job.coop_ring + tail + j, ((unsigned long long)job.coop_tag << 32) | NDT_COOP_CLOSE, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- consumers: one wavefront per SIMD (the first four of a workgroup) take the stragglers, one ray at a time
+        if ((int)(threadIdx.x >> 6) < consumers_per_block) {
+            const unsigned long long t_enter = wall_clock64();
+            unsigned int n_done = 0, t_coop = 0;
+            int ticket = -1, polls = 0;
+            while (true) {
+                unsigned long long e = 0ull;
+                if (lane == 0) {
+                    if (ticket < 0) ticket = atomicAdd(job.queue + NDT_COOP_HEAD, 1);
+                    e = __hip_atomic_load(job.coop_ring + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ticket = __shfl(ticket, 0, 64);
+                const unsigned int e_tag = (unsigned int)__shfl((int)(e >> 32), 0, 64), payload = (unsigned int)__shfl((int)e, 0, 64);
+                if (e_tag != job.coop_tag) {
+                    // not written yet (a slot beyond the tail is written when the launch closes)
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++polls & 1023) == 0 && wall_clock64() - t_enter > 200000000ull) break;   // 2 s: never on a healthy launch
+                    continue;
+                }
+                if (payload == NDT_COOP_CLOSE) break;
+                const unsigned long long t0 = job.coop_log ? wall_clock64() : 0ull;
+                const bool in_seg = (payload >> 31) != 0u;
+                const long long g = (long long)(payload & 0x7fffffffu);
+                const TracePart &part = in_seg ? job.seg : job.dense;
+                double o[N], v[N];
+                load_soa<N>(part.o, part.stride, g, o);
+                load_soa<N>(part.v, part.stride, g, v);
+                const double lim = part.lim ? part.lim[g] : -1.0;
+                // the next ticket travels while this ray is traced (issued behind the ray's loads: memory operations return in order)
+                ticket = 0;
+                if (lane == 0) ticket = atomicAdd(job.queue + NDT_COOP_HEAD, 1);
+                int obj, prim;
+                coop_trace<N>(blob, sd, o, v, lim, obj, prim);
+                if (lane == 0) {
+                    part.out_obj[g] = obj;
+                    part.out_prim[g] = prim;
+                }
+                if (job.coop_log) {
+                    ++n_done;
+                    t_coop += (unsigned int)(wall_clock64() - t0);
+                }
+            }
+            if (job.coop_log && lane == 0 && n_done) {
+                atomicAdd(job.coop_log + 1, n_done);
+                atomicAdd(job.coop_log + 2, t_coop);
+            }
         }
     }
     if (job.exit_log && lane == 0) {
         // one private slot per wavefront: shared counters would serialise the very exits they measure
         const unsigned int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-        if (4 * w + 3 < NDT_EXIT_LOG_WORDS) {
-            job.exit_log[4 * w] = probe_start;
-            job.exit_log[4 * w + 1] = probe_batch;
-            job.exit_log[4 * w + 2] = (unsigned int)wall_clock64() | 1u;
-            job.exit_log[4 * w + 3] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffffu) | ((blockDim.x / 64) << 24);   // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]; [31:24] wavefronts per workgroup
+        if (8 * w + 7 < NDT_EXIT_LOG_WORDS) {
+            job.exit_log[8 * w] = probe_start;
+            job.exit_log[8 * w + 1] = probe_batch;
+            job.exit_log[8 * w + 2] = (unsigned int)wall_clock64() | 1u;
+            job.exit_log[8 * w + 3] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffffu) | ((blockDim.x / 64) << 24);   // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]; [31:24] wavefronts per workgroup
+            job.exit_log[8 * w + 4] = probe_left | 1u;      // out of batches (with a straggler ring the wavefront stays on as a consumer)
         }
     }
 #ifdef NDT_PHASE_TIMING

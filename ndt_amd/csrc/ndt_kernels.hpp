@@ -48,6 +48,7 @@ struct Workspace {
     unsigned long long *dbg;        // [64] diagnostic accumulators (NDT_PHASE_TIMING builds only)
     unsigned int *exit_log;         // [NDT_EXIT_LOG_LAUNCHES][NDT_EXIT_LOG_WORDS], NDT_HIP_EXIT_PROBE
     unsigned int *shade_log;        // NDT_HIP_SHADE_PROBE: {start, end} per wavefront of ONE shade launch (set for that launch only)
+    unsigned long long *coop_ring;  // [NDT_COOP_RING_ENTRIES] straggler queue of the trace launches (TraceJob::coop_ring)
     LevelRange *levels;             // [NDT_MAX_LEVELS + 1] bounce table
     // the same table in host-visible (mapped, coherent) memory + one tag per entry: k_level_step
     // posts bounce b+1 here, the host polls the tag instead of synchronising the stream
@@ -110,8 +111,20 @@ struct TraceJob {
     int skip_trace;             // diagnostic build only: pop, load and store but do not traverse
     int tail_solo;              // the last this-many batches of every queue shard go to one wavefront per SIMD only (k_trace)
     unsigned int *exit_log;     // NDT_HIP_EXIT_PROBE: {start, start of the last batch, exit} per wavefront (100 MHz clock, low words)
+    // Cooperative stragglers (item-set tier; ndt_device.hpp:coop_trace): the rays a wavefront gives up on -- a batch over its
+    // budget with few rays left -- are queued in `coop_ring` and traced, one ray per wavefront, by the wavefronts that have run
+    // out of batches.  Entries: tag << 32 | payload (payload: ray slot, bit 31 = shadow part); a slot is valid for THIS launch
+    // when its tag is coop_tag, so the ring is never cleared.  The counters live behind the launch's queue heads (NDT_COOP_*).
+    unsigned long long *coop_ring;      // nullptr: off
+    unsigned int coop_tag;
+    int coop_limit;             // nothing is given up once the ring's tail has passed this (the ring has room for what is in flight beyond)
+    int coop_budget;            // 100 MHz ticks a batch may take before its last rays are given up
+    int coop_max_live;          // ... when at most this many are left
+    int coop_tail_only;         // ... and (when set) the batch's queue shard has run dry: only in the tail of the launch
+    int coop_waves;             // wavefronts of a workgroup that stay as consumers (4: one per SIMD)
+    unsigned int *coop_log;     // NDT_HIP_EXIT_PROBE: [0] rays given up, [1] rays traced cooperatively, [2] ticks spent in coop_trace
 };
-#define NDT_EXIT_LOG_WORDS 65536    /* per launch: 4 words {start, last batch, exit, HW_ID} x 16384 wavefronts */
+#define NDT_EXIT_LOG_WORDS 65536    /* per launch: 8 words {start, last batch, exit, HW_ID, out of batches, -, -, -} x 8192 wavefronts */
 #define NDT_EXIT_LOG_LAUNCHES 6
 #define NDT_SHADE_LOG_WAVES 131072  /* wavefronts the shade probe has slots for */
 
@@ -230,7 +243,17 @@ extern "C" const NdtKernelTable *ndt_kernel_table_12();
 #define NDT_QUEUE_SHARDS 64                 /* queue heads per launch (one lane reads one head); with 8 -- one per XCD -- 384 wavefronts shared a head */
 #endif
 #define NDT_QUEUE_STRIDE 16                 /* ints between heads: one 64-byte line each */
-#define NDT_QUEUE_INTS (NDT_QUEUE_SHARDS * NDT_QUEUE_STRIDE)
+/* behind the heads, one 64-byte line each: the straggler ring's tail and head, the wavefronts that have left the batch loop
+   per group of workgroups (blockIdx % 8), and the groups that are complete */
+#define NDT_COOP_TAIL (NDT_QUEUE_SHARDS * NDT_QUEUE_STRIDE)
+#define NDT_COOP_HEAD (NDT_COOP_TAIL + NDT_QUEUE_STRIDE)
+#define NDT_COOP_LEFT (NDT_COOP_HEAD + NDT_QUEUE_STRIDE)
+#define NDT_COOP_GROUPS 8
+#define NDT_COOP_GROUPS_DONE (NDT_COOP_LEFT + NDT_COOP_GROUPS * NDT_QUEUE_STRIDE)
+#define NDT_QUEUE_INTS (NDT_COOP_GROUPS_DONE + NDT_QUEUE_STRIDE)
+#define NDT_COOP_RING_LIMIT (1 << 20)       /* entries that may be given up per launch ... */
+#define NDT_COOP_RING_ENTRIES (NDT_COOP_RING_LIMIT + 8192 * 64 + 8192)   /* ... + what the wavefronts in flight can add beyond + one closing entry per consumer */
+#define NDT_COOP_CLOSE 0xfffffffeu          /* payload of the closing entries */
 #define NDT_CNT_QUEUE 16
 #define NDT_CNT_SEG (NDT_CNT_QUEUE + NDT_QUEUE_SLOTS * NDT_QUEUE_INTS)
 #define NDT_CNT_TOTAL (NDT_CNT_SEG + 128)         /* shadow-segment counters, double-buffered by bounce parity */

@@ -293,6 +293,43 @@ def test_item_sets_change_nothing(gpu, oracle, name):
     assert np.array_equal(got[2], want[2])
 
 
+COOP_CASES = ["c3_random4d", "zoo4d", "zoo3d_mirror", "c1_hypercube3d", "zoo5d_f2", "zoo6d"]
+
+
+@pytest.mark.parametrize("name", COOP_CASES)
+def test_cooperative_stragglers_change_nothing(gpu, name):
+    """Item-set scenes: the rays a batch of the trace kernel gives up are traced again, one ray per wavefront, by
+    coop_trace (every item against the ray side by side, then a scalar replay of trace() / kd_node_intersect).  Forced for
+    EVERY ray (budget 0, any number of rays left), for the last eight of every batch, and switched off: the reference's
+    trace_kd answers bit for bit, and the same frame -- pixels and ray counts -- as the default settings give."""
+    g = golden(name)
+    gpu.upload_scene(g.scene)
+    rays, want = g.data["kat_in"], g.data["kat_out"]
+    d = g.scene.dims
+    try:
+        gpu.set_option("pipeline", 1)           # the per-bounce kernels: the trace kernel that has the straggler ring
+        frames = {}
+        for label, (on, budget, live) in {"default": (1, 25, 8), "all": (1, 0, 64), "last8": (1, 0, 8), "off": (0, 25, 8)}.items():
+            gpu.set_option("coop", on)
+            gpu.set_option("coop_budget_us", budget)
+            gpu.set_option("coop_max_live", live)
+            obj, hit, nrm = gpu.trace_rays(rays)
+            assert np.array_equal(obj, want[:, 1].astype(np.int32)), label
+            assert np.array_equal(hit, want[:, 2:2 + d]), label
+            assert np.array_equal(nrm, want[:, 2 + d:2 + 2 * d]), label
+            out, st = gpu.render(g.width, g.height, g.depth)
+            frames[label] = (out, (st.rays_primary, st.rays_secondary, st.rays_shadow, st.rays_ref_equiv))
+        for label in ("all", "last8", "off"):
+            assert np.array_equal(frames[label][0], frames["default"][0]), label
+            assert frames[label][1] == frames["default"][1], label
+        assert np.abs(frames["all"][0] - g.data["fb"]).max() < TOL_TIGHT
+    finally:
+        gpu.set_option("pipeline", 0)
+        gpu.set_option("coop", 1)
+        gpu.set_option("coop_budget_us", 25)
+        gpu.set_option("coop_max_live", 8)
+
+
 @pytest.mark.parametrize("name", ["kat_hypercube6d", "kat_hypercube7d", "kat_hypercube8d"])
 def test_leaf_history_changes_nothing(gpu, oracle, name):
     """Global-memory tier (6-D .. 8-D hypercubes): a ray's visit mask is kept as up to four {leaf, cut} pairs tested against the
