@@ -61,7 +61,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ctx->device = device;
     {
         // the environment is read here, once: nothing on the render or upload path looks at it
-        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "shade_pair", "debug_levels",
+        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "item_sets", "gate_prepass", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "fuse_primaries", "shade_pair", "debug_levels",
                                              "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
         if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
@@ -158,6 +158,7 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
         if (value < 0 || value > 2) return fail(NDT_E_INVALID, "multi_path %lld", (long long)value);
         ctx->multi_path = (int)value;
     } else if (!strcmp(name, "stream_fused")) ctx->stream_fused = on;
+    else if (!strcmp(name, "fuse_primaries")) ctx->fuse_primaries = on;
     else if (!strcmp(name, "shade_pair")) ctx->shade_pair = on;
     else if (!strcmp(name, "debug_levels")) ctx->debug_levels = on;
     else if (!strcmp(name, "exit_probe")) ctx->exit_probe = on;
@@ -271,6 +272,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim; tj.begin = 0; tj.count = cnt; tj.levels = nullptr;
     tj.queue = ws.counters + NDT_CNT_QUEUE;
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
+    tj.publish_level = -1;
     coop_setup(ctx, tj, nullptr);
     ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);

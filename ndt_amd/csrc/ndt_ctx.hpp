@@ -84,6 +84,7 @@ struct ndt_hip_ctx {
     // ndt_hip_set_option / NDT_HIP_* at context creation (include/ndt_hip.h)
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
+    bool fuse_primaries = true;     // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary)
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
     // item sets: the min_dist-free part of every gate before the walk (ndt_device.hpp:trace_kd).  0 never, 1 always, 2 (default)

@@ -275,42 +275,6 @@ __global__ void k_stream_done(Workspace ws, StreamArgs sa, unsigned long long *d
     __hip_atomic_store(&done[7], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// After shade_emit(level) has spawned the next bounce: publish its range, note the shadow rays
-// this bounce emitted, and clear the other parity's segment counters for the next shade_emit.
-// The range is also posted to host-visible memory: k_level_step runs early in a bounce (before
-// its long trace launch), so by the time the host wants to enqueue the next bounce the answer
-// is there and the GPU never waits for the host.  One wavefront.
-__global__ void k_level_step(Workspace ws, int level, int n_seg, unsigned long long tag)
-{
-    const int lane = threadIdx.x;
-    int *seg = NDT_SEG_COUNTERS(ws, level);
-    long long mine = (lane < n_seg) ? seg[lane] : 0;
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    NDT_SEG_COUNTERS(ws, level + 1)[lane] = 0;
-    if (lane != 0) return;
-    const LevelRange cur = ws.levels[level];
-    ws.levels[level].n_shadow = mine;
-    LevelRange next;
-    next.begin = cur.begin + cur.count;
-    next.count = (long long)ws.counters[0] - next.begin;
-    next.n_shadow = 0;
-    if (next.count < 0 || ws.counters[2] != 0) next.count = 0;         // node pool overflow: the host retries
-    next.seg_stride = (next.count + 63) & ~63LL;
-    if ((long long)n_seg * next.seg_stride > ws.sh_cap) {
-        // the shadow queue cannot hold this bounce: flag it, tell the host how much it needs, stop here
-        atomicOr(&ws.counters[2], 2);
-        const long long need = (long long)n_seg * next.seg_stride;
-        ws.counters[3] = need > 0x7fffffffLL ? 0x7fffffff : (int)need;
-        next.count = 0;
-        next.seg_stride = 0;
-    }
-    ws.levels[level + 1] = next;
-    // ... and for the host, which enqueues bounce level+1 only once it knows there is one
-    ws.mail[level + 1] = next;
-    __threadfence_system();
-    __hip_atomic_store(&ws.mail_tag[level + 1], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // Bottom-up combine of one bounce: get_ray_color's blend of its own colour with the colours
 // its reflection / refraction children returned (ndt.c:402-429), in the reference's order.
 __device__ __forceinline__ void resolve_node(const double *blob, const SceneDesc &sd, const Workspace &ws, int specular, long long g)
@@ -649,7 +613,8 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         int queue_slot = 0;
         int launches = 0;
-        kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
+        // (no k_primary: the first trace launch makes the primaries it traces, TraceJob::make_primaries)
+        if (!ctx->fuse_primaries || ctx->coop) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             const bool exit_probe = ctx->exit_probe;
@@ -673,7 +638,12 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             tj.dense.o = ws.ray_o; tj.dense.v = ws.ray_v; tj.dense.stride = ws.cap; tj.dense.lim = nullptr;
             tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
             tj.begin = 0; tj.count = rg.n_primary; tj.levels = nullptr;
-            if ((rc = traced(tj, "closest 0"))) return rc;
+            tj.publish_level = -1;
+            if (ctx->fuse_primaries && !ctx->coop) {
+                tj.make_primaries = 1;
+                tj.rg = rg;
+            }
+            if ((rc = traced(tj, "primaries + closest 0"))) return rc;
         }
         long long upper = rg.n_primary;         // node count of the bounce
         std::vector<long long> level_nodes;
@@ -729,12 +699,12 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 pending_finish = -1;
             } else {
                 if (pending_finish >= 0) {
-                    kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+                    kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper, 0);
                     pending_finish = -1;
                 }
                 kt->shade_emit(s, ctx->d_blob, sd_pass, shade_ws(0), rg, b, upper);
             }
-            hipLaunchKernelGGL(k_level_step, dim3(1), dim3(64), 0, s, ws, b, n_seg, tag);
+            // (no k_level_step: the trace launch below publishes bounce b + 1, TraceJob::publish_level)
             long long next_upper = 2 * upper;           // each node spawns at most two
             if (next_upper > ws.cap) next_upper = ws.cap;
             {
@@ -750,12 +720,18 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 tj.begin = 0;
                 tj.count = next_upper;                          // sizes the grid only
                 tj.levels = ws.levels; tj.seg_level = b; tj.dense_level = (b + 1 == hand) ? -1 : b + 1;     // the frame kernel traces bounce `hand`
+                tj.publish_level = b;
+                tj.publish_tag = tag;
                 if ((rc = traced(tj, "shadow " + std::to_string(b) + (b + 1 == hand ? "" : " + closest " + std::to_string(b + 1))))) return rc;
             }
             pending_finish = b;
             pending_upper = upper;
         }
-        if (pending_finish >= 0) kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper);
+        // the lighting of the deepest bounce that has nodes: blended on the spot (its nodes have no child nodes), unless the frame
+        // kernel renders deeper bounces behind it (hybrid)
+        const bool resolve_with_finish = pending_finish >= 0 && !hybrid && pending_finish >= 1 && pending_finish == n_run - 1;
+        if (pending_finish >= 0)
+            kt->shade_finish(s, ctx->d_blob, sd_pass, shade_ws(pending_upper), rg, pending_finish, pending_upper, resolve_with_finish ? 1 : 0);
         StreamArgs sa = ctx->sa;
         hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
         if (hybrid && n_run >= hand && hand < n_levels) {
@@ -802,6 +778,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         // bottom-up colour resolve, deepest bounce first (the primaries last)
         {
             for (int b = n_run; b-- > 1;) {        // (bounce 0, the primaries: inside k_finish_pixels)
+                if (resolve_with_finish && b == n_run - 1) continue;
                 long long blocks = (level_nodes[b] + 255) / 256;
                 if (blocks > NDT_SHADE_MAX_BLOCKS) blocks = NDT_SHADE_MAX_BLOCKS;
                 hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, sd_pass, ws, rg.specular, b);

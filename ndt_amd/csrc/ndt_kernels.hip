@@ -279,6 +279,9 @@ __global__ void __launch_bounds__(256) k_primary(const double *blob, SceneDesc s
 
 // The visit mask of this lane's rays.  MW == 0: its words in the global slab (one column per resident lane) and, when the
 // scene carries them, the leaf sets of the history representation (ndt_device.hpp:VisitMask).
+// (the bounce table is the launch's to write where it publishes: TraceJob::publish_level)
+NDT_DEV LevelRange *job_levels_mut(const TraceJob &job) { return const_cast<LevelRange *>(job.levels); }
+
 template <int MW> NDT_DEV void init_visit_mask(VisitMask<MW> &mask, const double *gblob, const SceneDesc &sd, const Workspace &ws)
 {
     mask.ext = nullptr;
@@ -306,7 +309,10 @@ template <int MW> NDT_DEV void init_visit_mask(VisitMask<MW> &mask, const double
 // queue (one atomic per batch), so a wavefront that drew cheap rays (sky) immediately takes
 // more work instead of idling until the expensive tiles finish.  Every wavefront exits when
 // the queue head passes the ray count.
-template <int MW, bool LDS, bool LSTACK = false>
+// COOPK: the variant with the straggler ring (TraceJob::coop_ring; option `coop`); PRIM: the variant whose dense part is the
+// pass's primaries, made here (TraceJob::make_primaries).  Both are variants, not run-time branches: the code of either in the
+// kernel cost the launches that do not use it 2-3 % (registers and scratch around the traversal loop).
+template <int MW, bool LDS, bool LSTACK = false, bool COOPK = false, bool PRIM = false>
 __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_MAX_BLOCK) k_trace(const double *__restrict__ gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_blob[];
@@ -352,7 +358,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
     }
     const int lane = __lane_id();
     // cooperative stragglers (TraceJob::coop_ring): the item-set tier only
-    constexpr bool COOP = (MW == 1) && LDS;
+    constexpr bool COOP = COOPK && (MW == 1) && LDS;
     const bool coop_on = COOP && job.coop_ring != nullptr;
     // NDT_HIP_EXIT_PROBE: when does every wavefront start, start its last batch, and run out of work
     const unsigned int probe_start = job.exit_log ? (unsigned int)wall_clock64() : 0u;
@@ -379,14 +385,51 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
     }
     long long dense_count = job.count, dense_begin = job.begin, seg_stride = job.seg_stride;
     if (job.levels) {
-        // ranges produced earlier on this stream (k_level_step)
+        // The bounce whose shadow rays this launch traces was published earlier on this stream; the NEXT bounce -- its nodes are
+        // this launch's closest-hit part -- is published here (TraceJob::publish_level): its range is what the node tail says,
+        // the same for every wavefront that looks.
+        const LevelRange cur = job.levels[job.seg_level];
+        seg_stride = cur.seg_stride;
+        LevelRange next;
+        if (job.publish_level >= 0) {
+            next.begin = cur.begin + cur.count;
+            next.count = (long long)ws.counters[0] - next.begin;
+            next.n_shadow = 0;
+            if (next.count < 0 || (ws.counters[2] & 1) != 0) next.count = 0;        // node pool overflow: the host retries
+            next.seg_stride = (next.count + 63) & ~63LL;
+            const bool sh_overflow = (long long)job.n_seg * next.seg_stride > ws.sh_cap;
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                // the launch's first wavefront: the table, the other parity's segment counters, the host's mailbox
+                long long emitted = seg_cnt;
+                for (int d = 32; d > 0; d >>= 1) emitted += __shfl_xor(emitted, d, 64);
+                NDT_SEG_COUNTERS(ws, job.publish_level + 1)[lane] = 0;
+                if (lane == 0) {
+                    job_levels_mut(job)[job.publish_level].n_shadow = emitted;
+                    LevelRange out = next;
+                    if (sh_overflow) {
+                        // the shadow queue cannot hold the next bounce: flag it, tell the host how much it needs, stop here
+                        atomicOr(&ws.counters[2], 2);
+                        const long long need = (long long)job.n_seg * next.seg_stride;
+                        ws.counters[3] = need > 0x7fffffffLL ? 0x7fffffff : (int)need;
+                        out.count = 0;
+                        out.seg_stride = 0;
+                    }
+                    job_levels_mut(job)[job.publish_level + 1] = out;
+                    ws.mail[job.publish_level + 1] = out;
+                    __threadfence_system();
+                    __hip_atomic_store(&ws.mail_tag[job.publish_level + 1], job.publish_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            if (sh_overflow) next.count = 0;
+        } else {
+            next = job.levels[job.dense_level >= 0 ? job.dense_level : 0];
+        }
         if (job.dense_level >= 0) {
-            dense_begin = job.levels[job.dense_level].begin;
-            dense_count = job.levels[job.dense_level].count;
+            dense_begin = next.begin;
+            dense_count = next.count;
         } else {
             dense_count = 0;        // shadow rays only (the next bounce's nodes go to the frame kernel: hybrid pipeline)
         }
-        seg_stride = job.levels[job.seg_level].seg_stride;
     }
     const long long dense_batches = (dense_count + bs - 1) >> sh;
     const long long n_batches = dense_batches + seg_batches;
@@ -474,23 +517,30 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             const long long r = b * bs + lane;
             live = lane < bs && r < dense_count;
             g = dense_begin + (live ? r : 0);
-            if (live && job.dense.valid && job.dense.valid[g] <= 0) live = false;
+            if (!PRIM && live && job.dense.valid && job.dense.valid[g] <= 0) live = false;
         }
+        // The primaries of a pass are made HERE, by the wavefront that traces them (render_pixel + the head of get_pixel_color,
+        // ndt.c:578-653, 488-550: primary_node -- what the k_primary launch used to do: 2N doubles a ray written and read back
+        // before anything was traced); the node's record still goes to the pool for the kernels behind this one.
+        double o[N], v[N];
+        const bool make = PRIM && !in_seg;                      // (wave-uniform)
+        if (PRIM && make && live) live = primary_node<false>(gblob, sd, ws, job.rg, g, o, v);
         // A lane without a ray.  The LDS tiers leave it out of the batch; in the global-memory tier it stays with the
         // wavefront as a helper of the coherent leaf scan (ndt_device.hpp:cls_scan: all 64 lanes fetch), with a ray that is
         // finished before it starts.
         bool gave_up = false;
         if (live || MW == 0) {
         const TracePart &part = in_seg ? job.seg : job.dense;
-        double o[N], v[N];
 #ifdef NDT_TRACE_SKIP_KNOB
         if (job.skip_trace == 3) {
             for (int c = 0; c < N; ++c) { o[c] = (double)g; v[c] = 1.0; }
         } else
 #endif
         if (live) {
-        load_soa<N>(part.o, part.stride, g, o);
-        load_soa<N>(part.v, part.stride, g, v);
+            if (!make) {
+                load_soa<N>(part.o, part.stride, g, o);
+                load_soa<N>(part.v, part.stride, g, v);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < N; ++c) { o[c] = 0.0; v[c] = 0.0; }
@@ -626,6 +676,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
                 const long long g = (long long)(payload & 0x7fffffffu);
                 const TracePart &part = in_seg ? job.seg : job.dense;
                 double o[N], v[N];
+                // (a launch with the ring never makes its own primaries: what it is given up was stored by an earlier kernel)
                 load_soa<N>(part.o, part.stride, g, o);
                 load_soa<N>(part.v, part.stride, g, v);
                 const double lim = part.lim ? part.lim[g] : -1.0;
@@ -722,6 +773,7 @@ template <typename K> static int resident_blocks(K kernel, int block, size_t lds
         else                                                                                                   \
             hipLaunchKernelGGL((kernel), dim3((unsigned)(grid)), dim3(block), lds, s, blob, sd, ws, job);      \
     } while (0)
+typedef void (*TraceKernel)(const double *, SceneDesc, Workspace, TraceJob);
 static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, TraceJob job, int tier,
                          int mask_words, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
@@ -756,34 +808,44 @@ static void launch_trace(hipStream_t s, const double *blob, SceneDesc sd, Worksp
         int lstack_block = lstack_full;
         if (lstack_full >= 256 && upper / job.batch < small_launch) lstack_block = 256;
         const size_t lds_stack = ((size_t)((sd.trace_words + 1) & ~1) * 8) + (size_t)lstack_block * (sd.kd_depth + 1) * 12;
+        // the kernel's variant: with the straggler ring (item sets only), making its own primaries, or plain
+        const bool ring = job.coop_ring != nullptr && mask_words <= 1;
+        if (!ring) job.coop_ring = nullptr;
+        const bool prim = job.make_primaries != 0 && !ring;
         if (lstack_block >= 64 && mask_words <= 1 && lds_stack <= 160 * 1024) {
-            const int res = resident_blocks(k_trace<1, true, true>, lstack_block, lds_stack);
+            const TraceKernel kern = ring ? k_trace<1, true, true, true, false> : prim ? k_trace<1, true, true, false, true> : k_trace<1, true, true>;
+            const int res = resident_blocks(kern, lstack_block, lds_stack);
             long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
             if (nb > res) nb = res;
-            NDT_LAUNCH_TRACE((k_trace<1, true, true>), nb, lstack_block, lds_stack);
+            NDT_LAUNCH_TRACE(kern, nb, lstack_block, lds_stack);
         } else if (lstack_block >= 64 && mask_words > 1 && lds_stack <= 160 * 1024) {
             // scenes of 65 .. 256 objects (a register mask of four words): the same, with the wider mask
-            const int res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true, true>, lstack_block, lds_stack);
+            const TraceKernel kern = prim ? k_trace<NDT_MASK_REG_WORDS, true, true, false, true> : k_trace<NDT_MASK_REG_WORDS, true, true>;
+            const int res = resident_blocks(kern, lstack_block, lds_stack);
             long long nb = (upper + job.batch * (lstack_block / 64) - 1) / (job.batch * (lstack_block / 64));
             if (nb > res) nb = res;
-            NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true, true>), nb, lstack_block, lds_stack);
+            NDT_LAUNCH_TRACE(kern, nb, lstack_block, lds_stack);
         } else if (mask_words <= 1) {
-            const int res = resident_blocks(k_trace<1, true>, block, lds);
+            const TraceKernel kern = ring ? k_trace<1, true, false, true, false> : prim ? k_trace<1, true, false, false, true> : k_trace<1, true>;
+            const int res = resident_blocks(kern, block, lds);
             if (blocks > res) blocks = res;
-            NDT_LAUNCH_TRACE((k_trace<1, true>), blocks, block, lds);
+            NDT_LAUNCH_TRACE(kern, blocks, block, lds);
         } else {
-            const int res = resident_blocks(k_trace<NDT_MASK_REG_WORDS, true>, block, lds);
+            const TraceKernel kern = prim ? k_trace<NDT_MASK_REG_WORDS, true, false, false, true> : k_trace<NDT_MASK_REG_WORDS, true>;
+            const int res = resident_blocks(kern, block, lds);
             if (blocks > res) blocks = res;
-            NDT_LAUNCH_TRACE((k_trace<NDT_MASK_REG_WORDS, true>), blocks, block, lds);
+            NDT_LAUNCH_TRACE(kern, blocks, block, lds);
         }
     } else {
+        job.coop_ring = nullptr;
+        const TraceKernel kern_t1 = job.make_primaries ? k_trace<0, false, false, false, true> : k_trace<0, false>;
         // (coherent leaf scan: one LDS window per wavefront)
         const size_t lds = (size_t)(block / 64) * ((sd.off_obox > 0 ? N * 128 : 0) + (sd.cls_par_words > 0 ? cls_window_words<N>(sd.cls_par_words) : 0)) * sizeof(double);
-        const int res = resident_blocks(k_trace<0, false>, block, lds);
+        const int res = resident_blocks(kern_t1, block, lds);
         if (blocks > res) blocks = res;
         const long long max_blocks = ws.mask_slab_lanes / block;
         if (blocks > max_blocks) blocks = max_blocks;
-        NDT_LAUNCH_TRACE((k_trace<0, false>), blocks, block, lds);
+        NDT_LAUNCH_TRACE(kern_t1, blocks, block, lds);
     }
 }
 
@@ -1195,7 +1257,7 @@ __global__ void __launch_bounds__(NDT_EMIT_BLOCK) k_shade_emit(const double *blo
 // ------------------------------------------------------------------ shading, second half
 
 NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg,
-                               const LevelRange &lr, int level, long long r)
+                               const LevelRange &lr, int level, long long r, const bool resolve_here = false)
 {
     const bool in_range = r < lr.count;
     const long long g = lr.begin + (in_range ? r : 0);
@@ -1284,6 +1346,26 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
                 cb += hitr_b * lb_ / max_light * rvn;
             }
         }
+        if (resolve_here) {
+            // The deepest bounce of the frame: its nodes have no child nodes (a child there was cut off, -2: black, ndt.c:336-341),
+            // so get_ray_color's blend (ndt.c:402-429; ndt_frame.hip:resolve_node, same operations) needs nothing but this node
+            const double hitr[3] = { refl_r, refl_g, refl_b };
+            double c[3] = { cr, cg, cb };
+            if (ws.child_refl[g] != -1) {
+                const double ref = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (rg.specular) c[k] = (1 - hitr[k]) * (c[k]) + (hitr[k]) * ref;       // ndt.c:405-407
+                    else c[k] += hitr[k] * ref;                                             // ndt.c:411-413
+                }
+            }
+            if (ws.child_refr[g] != -1) {
+                const double ref = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c[k] += (1.0 - hitr[k]) * ref;                  // ndt.c:426-428
+            }
+            cr = c[0]; cg = c[1]; cb = c[2];
+        }
         ws.clr[0 * ws.cap + g] = cr;
         ws.clr[1 * ws.cap + g] = cg;
         ws.clr[2 * ws.cap + g] = cb;
@@ -1292,13 +1374,14 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
     }
 }
 
-__global__ void __launch_bounds__(256, NDT_SHADE_WAVES) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level)
+__global__ void __launch_bounds__(256, NDT_SHADE_WAVES) k_shade_finish(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
+                                                                       int resolve_here)
 {
     const LevelRange lr = ws.levels[level];
     const long long base = (long long)blockIdx.x * blockDim.x;
     if (base < lr.count) {
         NDT_SHADE_LOG_BEGIN();
-        shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x);
+        shade_finish_node(blob, sd, ws, rg, lr, level, base + threadIdx.x, resolve_here != 0);
         NDT_SHADE_LOG_END();
     }
 }
@@ -1371,10 +1454,11 @@ static void launch_shade_emit(hipStream_t s, const double *blob, SceneDesc sd, W
     if (upper <= 0) return;
     hipLaunchKernelGGL(k_shade_emit, dim3(grid_for(upper, NDT_EMIT_BLOCK)), dim3(NDT_EMIT_BLOCK), 0, s, blob, sd, ws, rg, level);
 }
-static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper)
+static void launch_shade_finish(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level, long long upper,
+                                int resolve_here)
 {
     if (upper <= 0) return;
-    hipLaunchKernelGGL(k_shade_finish, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level);
+    hipLaunchKernelGGL(k_shade_finish, dim3(shade_grid(upper)), dim3(256), 0, s, blob, sd, ws, rg, level, resolve_here);
 }
 static void launch_shade_pair(hipStream_t s, const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int level,
                               long long upper_finish, long long upper_emit)

@@ -123,6 +123,18 @@ struct TraceJob {
     int coop_tail_only;         // ... and (when set) the batch's queue shard has run dry: only in the tail of the launch
     int coop_waves;             // wavefronts of a workgroup that stay as consumers (4: one per SIMD)
     unsigned int *coop_log;     // NDT_HIP_EXIT_PROBE: [0] rays given up, [1] rays traced cooperatively, [2] ticks spent in coop_trace
+    // the dense part = the primaries of the pass `rg` describes, made by the wavefront that traces them (primary_node)
+    int make_primaries;
+    RenderGeom rg;
+    // The launch "shadow rays of bounce b + closest hits of bounce b + 1" also PUBLISHES bounce b + 1 (publish_level = b; -1: no):
+    // shade_emit(b) has just spawned it, so its range is what the node tail says -- every wavefront works it out for itself
+    // from the counters (final since the kernel boundary), and the first wavefront of the launch writes it to the bounce
+    // table, clears the other parity's segment counters and posts it to the host's mailbox (the host enqueues bounce b + 1
+    // only once it knows there is one).  Round 3 had a one-wavefront launch for this after every shading launch (12 us of
+    // stream time each); counting workgroups out of the shading launches instead (a "last one does it") cost every workgroup
+    // a returning atomic before it could leave, and more than it saved (profiles/experiments/README.md, round 4).
+    int publish_level;
+    unsigned long long publish_tag;
 };
 #define NDT_EXIT_LOG_WORDS 65536    /* per launch: 8 words {start, last batch, exit, HW_ID, out of batches, -, -, -} x 8192 wavefronts */
 #define NDT_EXIT_LOG_LAUNCHES 6
@@ -203,7 +215,8 @@ struct NdtKernelTable {
                   hipEvent_t ev_stop);
     // `upper` bounds the bounce's node count (sizes the grid); the range itself is ws.levels[level]
     void (*shade_emit)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
-    void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper);
+    // resolve_here: `level` is the deepest bounce of the frame, its nodes are blended on the spot (no k_resolve for it)
+    void (*shade_finish)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper, int resolve_here);
     // shade_finish(level) and shade_emit(level + 1) in one launch: they touch different nodes, and both are
     // short latency-bound kernels for the small deep bounces
     void (*shade_pair)(hipStream_t, const double *blob, SceneDesc, Workspace, RenderGeom, int level, long long upper_finish,
@@ -261,3 +274,5 @@ extern "C" const NdtKernelTable *ndt_kernel_table_12();
 #define NDT_SHADE_MAX_BLOCKS 8192            /* shade kernels walk longer bounces with a grid-stride loop */
 #define NDT_TRACE_LDS_LIMIT (64 * 1024)     /* bytes of scene staged per workgroup: two workgroups per CU */
 #define NDT_MASK_REG_WORDS 4                /* 64-bit words of visit mask kept in registers (256 items) */
+
+__device__ __forceinline__ int ndt_ld_cnt(const int *p) { return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

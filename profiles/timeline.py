@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(r['Kernel_Name'].split('(')[0][-34:], int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows]
 ks.sort(key=lambda x: x[1])
-idx = [i for i, k in enumerate(ks) if 'k_primary' in k[0]]
+idx = [i for i, k in enumerate(ks) if 'k_frame_init' in k[0]]
 i0, i1 = idx[-2], idx[-1]
 t0 = ks[i0][1]
 prev_end = t0

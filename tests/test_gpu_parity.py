@@ -325,7 +325,7 @@ def test_cooperative_stragglers_change_nothing(gpu, name):
         assert np.abs(frames["all"][0] - g.data["fb"]).max() < TOL_TIGHT
     finally:
         gpu.set_option("pipeline", 0)
-        gpu.set_option("coop", 1)
+        gpu.set_option("coop", 0)
         gpu.set_option("coop_budget_us", 25)
         gpu.set_option("coop_max_live", 8)
 
