@@ -116,8 +116,11 @@ def cpu_baseline(workload, width, height, depth, threads=16):
                     "sample": "%s %d-D %dx%d -l %d, whole frame once, reference render_image with %d pthreads "
                               "(%.2f s, %d trace_kd calls)" % (scene_so, dims, width, height, depth, cores, sec, rays),
                     "frame_s": sec, "rays": rays}
-        except Exception as e:  # fall through to the port
-            sys.stderr.write("cpu_baseline: reference run failed (%s); timing the oracle port\n" % e)
+        except Exception as e:  # fall through to the port, loudly: `kind` is what the reader trusts
+            sys.stderr.write("cpu_baseline: WARNING: the compiled reference failed (%s); timing the oracle PORT instead (kind: \"port\")\n" % e)
+    else:
+        sys.stderr.write("cpu_baseline: WARNING: oracle/_ref/ndt_ref_shim is missing (build it with `make -C oracle ref` where /root/reference "
+                         "exists); timing the oracle PORT instead (kind: \"port\")\n")
     from ndt_amd import load_scene, RenderParams, RenderStats
     so = os.path.join(ROOT, "oracle", "libndt_oracle.so")
     if not os.path.exists(so):
@@ -134,6 +137,7 @@ def cpu_baseline(workload, width, height, depth, threads=16):
     lib.ndt_oracle_render(fs.byref(), C.byref(p), buf.ctypes.data_as(C.c_void_p), C.byref(st), C.c_int(cores), C.c_int(1))
     sec = time.time() - t0
     return {"value": st.rays_ref_equiv / sec / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "degraded": "the compiled reference (oracle/_ref) was not available on this box: this is the oracle port's time",
             "sample": "%s %dx%d -l %d, every %d-th row, oracle port with literal re-sampling, %d threads" % (
                 fixture, width, height, depth, p.row_step, cores),
             "frame_s": sec * p.row_step, "rays": int(st.rays_ref_equiv)}

@@ -343,6 +343,12 @@ int ndt_hip_hcube_face_boxes(const ndt_flat_scene *scene, int32_t object, double
  * face_rows: n_faces x dims x { centre, half extent }, possible: one byte per face.  Returns the number of faces; with
  * cap_faces too small (or null pointers) only that -- call again with room.  0: the hcube gets no boxes, <0 on NDT_E_*. */
 int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *scene, int32_t object, int64_t cap_faces, double *face_rows, uint8_t *possible);
+/* Diagnostic, host only: the hierarchy the library lays over the face boxes of an hcube of more than 63 faces (option
+ * "face_tree"): level j = 1 .. *top holds, for every aligned run [k 2^j, (k + 1) 2^j) of faces, the box of the union of the
+ * boxes of its faces that can be hit (half extents of -1: none can); a ray that misses a run's box skips its faces.
+ * rows: n_nodes x dims x { centre, half extent }, level j starting at node level_off[j] (level_off: room for 32 ints).
+ * Returns the number of nodes; with cap_nodes too small (or rows null) only that and *top.  0: no boxes, <0 on NDT_E_*. */
+int64_t ndt_hip_hcube_face_tree(const ndt_flat_scene *scene, int32_t object, int64_t cap_nodes, double *rows, int32_t *level_off, int32_t *top);
 
 /* Diagnostic, host only: the item boxes the library derives at upload for scenes of more than 256 items -- one orthonormal
  * frame for the scene (frame: dims x unit axis[dims]) and, for every top-level orthotope, the box in that frame of every

@@ -38,6 +38,27 @@ extern "C" int ndt_hip_hcube_face_boxes(const ndt_flat_scene *fs, int32_t object
     return hf.n_faces;
 }
 
+extern "C" int64_t ndt_hip_hcube_face_tree(const ndt_flat_scene *fs, int32_t object, int64_t cap_nodes, double *rows_out, int32_t *level_off, int32_t *top_out)
+{
+    std::vector<double> hull((size_t)(fs ? fs->dims : 1) * (fs ? fs->dims + 2 : 1));
+    const int rc = ndt_hip_hcube_hull_box(fs, object, hull.data());      // validates the arguments
+    if (rc <= 0) return rc;
+    if (!level_off || !top_out) return fail(NDT_E_INVALID, "null argument");
+    std::vector<double> rows;
+    HullFaces hf;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    std::vector<double> trows;
+    std::vector<int> loff;
+    int top = 0;
+    hcube_face_tree(hf, fs->dims, trows, loff, top);
+    const int64_t n_nodes = (int64_t)(trows.size() / (2 * (size_t)fs->dims));
+    *top_out = top;
+    if (!rows_out || cap_nodes < n_nodes) return n_nodes;                // (how many: call again with room for them)
+    for (int j = 0; j <= top && j < 32; ++j) level_off[j] = loff[(size_t)j];
+    memcpy(rows_out, trows.data(), trows.size() * sizeof(double));
+    return n_nodes;
+}
+
 extern "C" int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *fs, int32_t object, int64_t cap_faces, double *face_rows, uint8_t *possible)
 {
     std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
@@ -286,6 +307,61 @@ static bool face_region_corners(const double *pos, const double *dir, int m, int
         pts.insert(pts.end(), pt.begin(), pt.end());
     }
     return true;
+}
+
+// The hierarchy over an hcube's face boxes (ndt_device.hpp:hull_faces, NDT_F_FACETREE): level j, node k = the box of the union
+// of the boxes of faces [k 2^j, (k + 1) 2^j) that can be hit at all; a run without such a face gets half extents of -1.
+// level_off[j] (j = 1 .. top): first node of level j in `rows` (2n doubles a node); level 0 is the faces' own rows.
+void ndt_impl::hcube_face_tree(const HullFaces &hf, int n, std::vector<double> &rows, std::vector<int> &level_off, int &top)
+{
+    const int nf = hf.n_faces;
+    top = 0;
+    while ((1 << top) < nf) ++top;
+    level_off.assign((size_t)top + 1, 0);
+    rows.clear();
+    // lo / hi of the level below (level 0: from the faces' { centre, half })
+    std::vector<double> lo((size_t)nf * n), hi((size_t)nf * n);
+    std::vector<char> any((size_t)nf, 0);
+    for (int f = 0; f < nf; ++f) {
+        any[(size_t)f] = (char)((hf.possible[(size_t)f / NDT_HULL_CHUNK] >> (f % NDT_HULL_CHUNK)) & 1ull);
+        for (int a = 0; a < n; ++a) {
+            const double c = hf.rows[((size_t)f * n + a) * 2], h = hf.rows[((size_t)f * n + a) * 2 + 1];
+            lo[(size_t)f * n + a] = c - h;
+            hi[(size_t)f * n + a] = c + h;
+        }
+    }
+    int cnt = nf;
+    for (int j = 1; j <= top; ++j) {
+        const int up = (cnt + 1) / 2;
+        std::vector<double> nlo((size_t)up * n), nhi((size_t)up * n);
+        std::vector<char> nany((size_t)up, 0);
+        level_off[(size_t)j] = (int)(rows.size() / (2 * (size_t)n));
+        for (int k = 0; k < up; ++k) {
+            for (int a = 0; a < n; ++a) {
+                double l = 1e300, h = -1e300;
+                for (int c = 2 * k; c < 2 * k + 2 && c < cnt; ++c)
+                    if (any[(size_t)c]) {
+                        if (lo[(size_t)c * n + a] < l) l = lo[(size_t)c * n + a];
+                        if (hi[(size_t)c * n + a] > h) h = hi[(size_t)c * n + a];
+                        nany[(size_t)k] = 1;
+                    }
+                nlo[(size_t)k * n + a] = l;
+                nhi[(size_t)k * n + a] = h;
+                if (nany[(size_t)k]) {
+                    // (centre +- half must hold [l, h] whatever the rounding of the two: a nanometre more)
+                    rows.push_back(0.5 * (l + h));
+                    rows.push_back(0.5 * (h - l) + 1e-9 * (1.0 + fabs(l) + fabs(h)));
+                } else {
+                    rows.push_back(0.0);
+                    rows.push_back(-1.0);
+                }
+            }
+        }
+        lo.swap(nlo);
+        hi.swap(nhi);
+        any.swap(nany);
+        cnt = up;
+    }
 }
 
 bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces)
@@ -764,6 +840,21 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
                     flags |= NDT_F_FACEBOX;
                     for (unsigned long long w : hf.possible) b.push_ints((int)(w & 0xffffffffull), (int)(w >> 32));
                     for (double x : hf.rows) b.push(x);
+                    if (hf.n_faces > NDT_HULL_CHUNK && ctx->face_tree) {
+                        // ... + the hierarchy over them: { top level, 0 }, the levels' offsets (ints, two a word, in words
+                        // from here), the rows of levels 1 .. top
+                        flags |= NDT_F_FACETREE;
+                        std::vector<double> trows;
+                        std::vector<int> loff;
+                        int top = 0;
+                        hcube_face_tree(hf, n, trows, loff, top);
+                        const int table_words = 1 + (top + 2) / 2;
+                        b.push_ints(top, 0);
+                        for (int j = 0; j <= top; j += 2)
+                            b.push_ints(j >= 1 ? table_words + loff[(size_t)j] * 2 * n : 0,
+                                        j + 1 <= top ? table_words + loff[(size_t)j + 1] * 2 * n : 0);
+                        for (double x : trows) b.push(x);
+                    }
                 }
             } else {
                 b.push(0.0);
@@ -939,7 +1030,8 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
             bool plain = ctx->leaf_scan;
             for (int id : leaf_list)
                 if (fs->objects[id].type == NDT_OBJ_HCUBE) plain = false;
-            if (plain && max_param_words <= NDT_CLS_MAX_PAR_WORDS) sd.cls_par_words = (max_param_words + 1) & ~1;
+            // (a record travels as two words per lane: the sphere's n + 2 words and the parameters must fit 128)
+            if (plain && max_param_words + n + 2 <= 128) sd.cls_par_words = (max_param_words + 1) & ~1;
             sd.cls_min_group = ctx->leaf_scan_group;
         }
     }

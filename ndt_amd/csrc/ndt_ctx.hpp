@@ -84,6 +84,7 @@ struct ndt_hip_ctx {
     // ndt_hip_set_option / NDT_HIP_* at context creation (include/ndt_hip.h)
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
+    bool face_tree = true;          // hcubes of more than 63 faces: a hierarchy over the face boxes (ndt_device.hpp:hull_faces)
     bool fuse_primaries = true;     // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary)
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
@@ -110,6 +111,8 @@ struct ndt_hip_ctx {
     int shade_probe = -1;           // the k-th shade launch of a frame logs its wavefronts (-1: none)
     long long sa_cap = 0, sa_sh_cap = 0;
     int sa_nseg = 0;
+    void *d_eyes = nullptr;         // the two eye images of a stochastic anaglyph render (ndt_sampled.hip)
+    size_t d_eyes_bytes = 0;
     void *d_out = nullptr;          // staging for ndt_hip_render (host output)
     size_t d_out_bytes = 0;
     void *d_shard = nullptr;        // ndt_hip_render_multi: this context's rows before they are pushed into the frame
@@ -156,6 +159,7 @@ struct HullFaces {
     int n_faces = 0;
 };
 bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);
+void hcube_face_tree(const HullFaces &hf, int n, std::vector<double> &rows, std::vector<int> &level_off, int &top);
 bool scene_item_boxes(const ndt_flat_scene *fs, int n, std::vector<double> &frame, std::vector<double> &rows, std::vector<char> &has);
 int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs);
 

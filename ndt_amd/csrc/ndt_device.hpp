@@ -29,6 +29,7 @@
 #define NDT_F_BOX         0x1000    /* hcube: hull box rows at its parameter offset (ndt_blob.hip:hcube_hull_box) */
 #define NDT_F_FACEBOX     0x2000    /* ... followed by the mask of possible faces and every face's own box in that frame */
 #define NDT_F_OBOX        0x4000    /* the item carries a box in the scene's frame (ndt_blob.hip:scene_item_boxes) */
+#define NDT_F_FACETREE    0x8000    /* hcube of more than 63 faces: behind the face boxes, the boxes of every aligned run of 2^j faces (hull_faces) */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
 // light_type numbering of the reference, scene.h:23-31
@@ -712,8 +713,42 @@ NDT_DEV bool slab_interval_holds(double lo, double hi)
 // (more than 63 faces: the masks come 63 faces at a time -- `chunk` is where to start looking and, on return, the chunk of the
 // mask that came back: the first one from there on in which the ray meets a face's box)
 #define NDT_HULL_CHUNK 63
+// Hcubes of more than 63 faces carry a hierarchy over their face boxes (NDT_F_FACETREE; round 4): level j holds, for every
+// aligned run [k 2^j, (k + 1) 2^j) of faces, the box of the union of their boxes.  The faces of an hcube come in groups of
+// 2^(N - m) consecutive ones that share their m directions and differ in the corner they hang on, low dimensions first
+// (hcube.c:33-153) -- so a run of 2^j of them is thin in the N - m - j dimensions its faces agree on, and a ray that is not within
+// the margin of that many planes at once misses the run as a whole.  The walk below visits the runs in face order (an in-order
+// descent of an implicit binary tree over the face numbers, no stack: at face i the largest aligned run that starts there is
+// tried, then -- the ray meeting it -- its halves), so the faces it reports come out ascending, as the scan needs them.  A ray
+// that meets the hull of the 10-D zoo's hcube used to test all 52 904 face boxes; now a few thousand runs.
 template <int N>
-NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N], int &chunk)
+NDT_DEV bool hull_box_meets(const double *blob, int q, const double (&po)[N], const double (&inv)[N])
+{
+    if (blob[q + 1] < 0.0) return false;            // (a run none of whose faces can be hit: half extent -1)
+    double f0 = 0.0, f1 = NDT_DBL_MAX;
+    bool fok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (fok) {
+            const double a = po[k] - blob[q + 2 * k];
+            const double h = blob[q + 2 * k + 1];
+            if (inv[k] == 0.0) {
+                if (fabs(a) > h) fok = false;
+            } else {
+                const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                const double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                if (lo > f0) f0 = lo;
+                if (hi < f1) f1 = hi;
+            }
+            if (k & 1) fok = fok && slab_interval_holds(f0, f1);
+        }
+    }
+    return fok && slab_interval_holds(f0, f1);
+}
+
+template <int N>
+NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N], int &chunk,
+                             const bool face_tree = false)
 {
     double po[N], inv[N];       // u_k.o and 1/(u_k.v); 0 marks a ray parallel to slab k
     double t0 = 0.0, t1 = NDT_DBL_MAX;
@@ -749,6 +784,40 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
     if (!face_boxes) return -1;
     const int fr = p + N * (N + 2);
     const int n_chunks = (nf + NDT_HULL_CHUNK - 1) / NDT_HULL_CHUNK;
+    if (face_tree) {
+        // the faces whose box the ray meets, from face 63 `chunk` on, in face order: the first one names the chunk that is
+        // reported, the walk goes on to that chunk's end
+        const int tree = fr + n_chunks + nf * 2 * N;            // { levels, offset of level 1 .. } then the levels' rows
+        const int top = blob_int(blob, tree, 0);                // the highest level (2^top >= nf)
+        int i = chunk * NDT_HULL_CHUNK;
+        int found = -1;
+        unsigned long long live = 0ull;
+        while (i < nf && (found < 0 || i < (found + 1) * NDT_HULL_CHUNK)) {
+            int j = (i == 0) ? top : (__ffs(i) - 1);
+            if (j > top) j = top;
+            bool moved = false;
+            while (!moved) {
+                const int q = (j == 0) ? fr + n_chunks + i * 2 * N : tree + blob_int(blob, tree + 1 + (j >> 1), j & 1) + (i >> j) * 2 * N;
+                if (!hull_box_meets<N>(blob, q, po, inv)) {
+                    i += 1 << j;                                // the whole run is missed
+                    moved = true;
+                } else if (j == 0) {
+                    const bool possible = (((unsigned long long)__double_as_longlong(blob[fr + i / NDT_HULL_CHUNK]) >> (i % NDT_HULL_CHUNK)) & 1ull) != 0ull;
+                    if (possible) {
+                        if (found < 0) found = i / NDT_HULL_CHUNK;
+                        if (i / NDT_HULL_CHUNK == found) live |= 1ull << (i - found * NDT_HULL_CHUNK);
+                    }
+                    i += 1;
+                    moved = true;
+                } else {
+                    --j;                                        // its first half starts at the same face
+                }
+            }
+        }
+        if (found < 0) return 0;
+        chunk = found;
+        return (long long)live;
+    }
     for (; chunk < n_chunks; ++chunk) {
         const int f_begin = chunk * NDT_HULL_CHUNK, f_end = (f_begin + NDT_HULL_CHUNK < nf) ? f_begin + NDT_HULL_CHUNK : nf;
         unsigned long long live = 0ull;
@@ -1042,7 +1111,7 @@ struct ClsLds {
 // 64 entries, 64 x {param_off, words | m << 16}, 64 axis orders, 64 x 2N words (an item's box rows, or its bounding sphere when it has no
 // box), two records (2 header words + the sphere + par_words of parameters each)
 template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words); }
-#define NDT_CLS_MAX_PAR_WORDS (128 - 12)     /* sphere + parameters are fetched as two words per lane (N <= 10) */
+/* sphere (N + 2 words) + parameters are fetched as two words per lane: 128 words a record (ndt_blob.hip:build_blob checks it per N) */
 
 NDT_DEV void cls_lds_sync()
 {
@@ -1608,7 +1677,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     int chunk = (sub_i - first) / NDT_HULL_CHUNK;
                     if (oflags & NDT_F_BOX)
                         live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * sub_owner, 1),
-                                             (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk);
+                                             (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk, (oflags & NDT_F_FACETREE) != 0);
                     if (live == 0) {
                         // (an hcube just entered: it never began -- no result to apply, the scan goes on in this very step)
                         if (fresh_hcube) in_sub = false;
@@ -1900,7 +1969,7 @@ NDT_DEV void coop_trace(const double *blob, const SceneDesc &sd, const double (&
                     if (live == 0 && !all_faces) {
                         long long lv = -1;
                         int ch = chunk;
-                        if (flags & NDT_F_BOX) lv = hull_faces<N>(blob, pbox, (flags & NDT_F_FACEBOX) != 0, nf, o, v, ch);
+                        if (flags & NDT_F_BOX) lv = hull_faces<N>(blob, pbox, (flags & NDT_F_FACEBOX) != 0, nf, o, v, ch, (flags & NDT_F_FACETREE) != 0);
                         if (lv == 0) {
                             cube_open = false;          // the ray misses the hull box, or every face box from `chunk` on
                         } else if (lv == -1) {

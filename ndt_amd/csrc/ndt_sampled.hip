@@ -258,19 +258,28 @@ int ndt_impl::render_sampled(ndt_hip_ctx *ctx, const ndt_render_params *p, void 
     // anaglyph (ndt.c:636-647): every pixel runs get_pixel_color for the left eye, then for the right; the depth map is the left's
     const int rows = ndt_hip_shard_rows(p->height, p->row_begin, p->row_step);
     const long long n_pixels = (long long)rows * p->width;
-    double *left = nullptr, *right = nullptr;
-    // (the eyes' scratch images are plain allocations: render_sampled_eye's own AaBuffers walks the context's pool from its start)
-    HIP_TRY(hipMalloc(&left, (size_t)n_pixels * 4 * sizeof(double)));
-    hipError_t e = hipMalloc(&right, (size_t)n_pixels * 4 * sizeof(double));
-    int rc = e == hipSuccess ? NDT_OK : fail(NDT_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    if (!rc) rc = render_sampled_eye(ctx, p, 0, 0, 0ull, left, total, d_depth);
+    // The eyes' scratch images: one allocation the context keeps (grown when a frame needs more), not a hipMalloc / hipFree pair a
+    // frame -- each of those synchronises the device and stalls every other context on it.  (Not from the AaBuffers pools:
+    // render_sampled_eye walks those from their start.)
+    const size_t eye_bytes = (size_t)n_pixels * 4 * sizeof(double);
+    if (ctx->d_eyes_bytes < 2 * eye_bytes) {
+        if (ctx->d_eyes) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_eyes);
+            ctx->d_eyes = nullptr;
+            ctx->d_eyes_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&ctx->d_eyes, 2 * eye_bytes);
+        if (e != hipSuccess) return fail(NDT_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+        ctx->d_eyes_bytes = 2 * eye_bytes;
+    }
+    double *left = (double *)ctx->d_eyes, *right = left + (size_t)n_pixels * 4;
+    int rc = render_sampled_eye(ctx, p, 0, 0, 0ull, left, total, d_depth);
     if (!rc) rc = render_sampled_eye(ctx, p, 2, 0, 0x5eed0000000000ffull, right, total, nullptr);
     if (!rc) {
         launch_anaglyph(ctx->stream, left, right, (double *)d_rgba, n_pixels);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(NDT_E_DEVICE, "anaglyph mix");
     }
-    (void)hipFree(left);
-    if (right) (void)hipFree(right);
     return rc;
 }
 

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
-    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes", "ndt_hip_hcube_face_boxes_all",
+    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes", "ndt_hip_hcube_face_boxes_all", "ndt_hip_hcube_face_tree",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
     "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
     "ndt_hip_item_boxes", "ndt_hip_render_rgba8_async", "ndt_hip_render_rgba8_wait",
@@ -73,6 +73,8 @@ def load_library():
     lib.ndt_hip_hcube_face_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.restype = C.c_int64
+    lib.ndt_hip_hcube_face_tree.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ndt_hip_hcube_face_tree.restype = C.c_int64
     lib.ndt_hip_render_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -132,6 +134,29 @@ def hcube_face_boxes(fs, obj):
     rc = lib.ndt_hip_hcube_face_boxes_all(fs.byref(), int(obj), count, rows.ctypes.data, possible.ctypes.data)
     assert rc == count
     return rows[:, :, 0].copy(), rows[:, :, 1].copy(), possible.astype(bool)
+
+
+def hcube_face_tree(fs, obj):
+    """The hierarchy over the face boxes of hcube `obj` (host only, no GPU): a list, level j = 1 .. top, of
+    (centre[K_j, N], half[K_j, N]) for the aligned runs of 2^j faces; None when the hcube gets no face boxes."""
+    import numpy as np
+    lib = load_library()
+    n = fs.dims
+    top = C.c_int32(0)
+    off = (C.c_int32 * 32)()
+    count = lib.ndt_hip_hcube_face_tree(fs.byref(), int(obj), 0, None, off, C.byref(top))
+    if count < 0:
+        raise NdtHipError(int(count), (lib.ndt_hip_last_error() or b"").decode())
+    if count == 0:
+        return None
+    rows = np.zeros((count, n, 2), dtype=np.float64)
+    rc = lib.ndt_hip_hcube_face_tree(fs.byref(), int(obj), count, rows.ctypes.data, off, C.byref(top))
+    assert rc == count
+    levels = []
+    for j in range(1, top.value + 1):
+        end = off[j + 1] if j < top.value else count
+        levels.append((rows[off[j]:end, :, 0].copy(), rows[off[j]:end, :, 1].copy()))
+    return levels
 
 
 class NdtHip:

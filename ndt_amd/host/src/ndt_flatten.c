@@ -106,6 +106,12 @@ static void flatten_node(ndt_flat_builder *fb, const ndt_kd_node *n, int me)
  * already non-zero -- the same numbers, the same order of everything else.  6 560 fits for the 8-D hypercube: 1.1 s on one
  * thread. */
 typedef struct { object **objs; int n, begin, step; } fit_job;
+static int cmp_object_ptr(const void *a, const void *b)
+{
+    const object *x = *(object *const *)a, *y = *(object *const *)b;
+    return (x > y) - (x < y);
+}
+
 static void *fit_worker(void *arg)
 {
     fit_job *j = (fit_job *)arg;
@@ -174,7 +180,13 @@ int ndt_flatten_scene_mt(scene *scn, ndt_flat_builder *fb, char *err, int err_le
             }
             /* (an hcube's own sphere is left to the loop below: it is fitted after its faces, on this thread) */
         }
-        fit_bounds_parallel(fit, n_fit, threads);
+        /* an object reachable twice (the same pointer in two clusters, or as a scene object and a cluster member) must be fitted
+         * by ONE thread: the reference serialises the lazy fit under a lock (object.c:610).  Sort the pointers, keep one of each. */
+        qsort(fit, (size_t)n_fit, sizeof(object *), cmp_object_ptr);
+        int n_uniq = 0;
+        for (int i = 0; i < n_fit; ++i)
+            if (n_uniq == 0 || fit[n_uniq - 1] != fit[i]) fit[n_uniq++] = fit[i];
+        fit_bounds_parallel(fit, n_uniq, threads);
         free(fit);
     }
     /* kd items first, in id order: the visit mask is indexed by this position */

@@ -66,8 +66,8 @@ static int render_any(scene *scn, int width, int height, int samples, int aa_dif
     char err[256];
     ndt_flat_builder fb;
     /* NDT_HOST_TIMING=1: where a frame's host time goes (stderr) */
-    static int timing = -1;
-    if (timing < 0) timing = getenv("NDT_HOST_TIMING") != NULL;
+    /* (read per call: a static written by concurrent host threads -- ndt_hip -j K -- would be a data race) */
+    const int timing = getenv("NDT_HOST_TIMING") != NULL;
     struct timespec ts0, ts1, ts2, ts3;
     if (timing) clock_gettime(CLOCK_MONOTONIC, &ts0);
     if (ndt_flatten_scene_mt(scn, &fb, err, sizeof(err), threads) != 0) {

@@ -123,6 +123,60 @@ def test_every_oracle_hit_on_an_hcube_lies_inside_a_face_box(oracle, name):
     assert checked > 15
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_face_tree_runs_hold_their_faces(oracle, name):
+    """The hierarchy over the face boxes of an hcube of more than 63 faces (ndt_hip_hcube_face_tree): the box of every aligned
+    run of 2^j faces holds the boxes of its faces that can be hit -- so a ray that misses a run misses them all -- and every
+    hit the reference reports lies inside the run of every level that its face belongs to."""
+    from ndt_amd.hip import hcube_hull_box, hcube_face_boxes, hcube_face_tree
+    fs = golden(name).scene
+    big = [h for h in hcubes(fs) if fs.objects[h]["n_obj"] > 63]
+    if not big:
+        pytest.skip("no hcube of more than 63 faces in this scene")
+    boxes = {h: hcube_hull_box(fs, h) for h in big}
+    checked = 0
+    for h in big:
+        faces, tree = hcube_face_boxes(fs, h), hcube_face_tree(fs, h)
+        if faces is None:
+            assert tree is None
+            continue
+        centre, half, live = faces
+        nf = len(centre)
+        assert len(tree) == int(np.ceil(np.log2(nf)))
+        lo, hi = centre - half, centre + half
+        for j, (c, hh) in enumerate(tree, start=1):
+            assert len(c) == (nf + (1 << j) - 1) >> j
+            for k in range(len(c)):
+                members = np.flatnonzero(live[k << j:(k + 1) << j]) + (k << j)
+                if len(members) == 0:
+                    assert (hh[k] < 0).all()
+                    continue
+                assert (c[k] - hh[k] <= lo[members].min(axis=0)).all() and (c[k] + hh[k] >= hi[members].max(axis=0)).all()
+        checked += 1
+    assert checked > 0
+    # the reference's hits, in every run above their face
+    rays = aimed_rays(fs, boxes.get, seed=31)
+    obj, hit, _ = oracle.trace(fs, rays)
+    n_in = 0
+    for h in big:
+        sel = obj == h
+        faces, tree = hcube_face_boxes(fs, h), hcube_face_tree(fs, h)
+        if faces is None or not sel.any():
+            continue
+        ax = boxes[h][0]
+        centre, half, live = faces
+        coord = hit[sel] @ ax.T
+        for x in coord:
+            inside = np.flatnonzero((np.abs(x[None] - centre) <= (half - SLACK)).all(axis=1) & live)
+            assert len(inside) > 0
+            ok = False
+            for f in inside:        # (the face that was hit is one of them: its runs must all hold the point)
+                ok = ok or all((np.abs(x - c[f >> j]) <= hh[f >> j]).all() for j, (c, hh) in enumerate(tree, start=1))
+            assert ok
+            n_in += 1
+    print("%s: %d reference hits on hcubes of more than 63 faces, all inside their runs" % (name, n_in))
+
+
 def test_hull_box_of_a_non_hcube_is_an_error():
     from ndt_amd.hip import hcube_hull_box, NdtHipError
     fs = golden("c3_random4d").scene
@@ -152,12 +206,17 @@ def test_cull_changes_nothing_on_the_device(oracle, name):
         gpu.upload_scene(fs)
         hull_only = gpu.trace_rays(rays)
         gpu.set_option("face_box", 1)
+        gpu.set_option("face_tree", 0)                  # face boxes walked linearly, 63 at a time (hcubes of more than 63 faces)
+        gpu.upload_scene(fs)
+        no_tree = gpu.trace_rays(rays)
+        gpu.set_option("face_tree", 1)
     finally:
         gpu.close()
-    for a, b, c, d in zip(got, plain, want, hull_only):
+    for a, b, c, d, e in zip(got, plain, want, hull_only, no_tree):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)
         assert np.array_equal(a, d)
+        assert np.array_equal(a, e)
 
 
 def axis_rays(fs, seed):
