@@ -1,5 +1,5 @@
 """Frame time with and without the first trace launch making its own primaries (option fuse_primaries), per-bounce kernels.
-usage: python profiles/fusion_probe.py [WxH] [shard]"""
+usage: python profiles/fusion_probe.py [WxH] [shard] [--opt=name]   (default option: fuse_primaries)"""
 import os
 import sys
 import time
@@ -9,6 +9,7 @@ from ndt_amd import load_scene
 from ndt_amd.hip import NdtHip
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+opt = ([a[6:] for a in sys.argv[1:] if a.startswith("--opt=")] or ["fuse_primaries"])[0]
 w, h = (int(x) for x in (args[0] if args else "1920x1080").split("x"))
 shard = int(args[1]) if len(args) > 1 else 1
 rows = (h + shard - 1) // shard
@@ -19,7 +20,7 @@ for scene, depth in (("c3_random4d", 4), ("c2_balls4d", 4), ("c1_hypercube3d", 1
     g.upload_scene(fs)
     g.set_option("pipeline", 1)
     for fuse in (0, 1, 0, 1):
-        g.set_option("fuse_primaries", fuse)
+        g.set_option(opt, fuse)
         for _ in range(3):
             g.render_device(buf.data_ptr(), w, h, depth, row_begin=0, row_step=shard)
         torch.cuda.synchronize()
@@ -31,5 +32,5 @@ for scene, depth in (("c3_random4d", 4), ("c2_balls4d", 4), ("c1_hypercube3d", 1
                 st = g.render_device(buf.data_ptr(), w, h, depth, row_begin=0, row_step=shard)
             torch.cuda.synchronize()
             best = min(best, 1e3 * (time.perf_counter() - t0) / n)
-        print("%s %dx%d r::%d fuse_primaries %d: %.3f ms a frame" % (scene, w, h, shard, fuse, best), flush=True)
+        print("%s %dx%d r::%d %s %d: %.3f ms a frame" % (scene, w, h, shard, opt, fuse, best), flush=True)
     g.close()
