@@ -73,8 +73,9 @@ def load_library():
     lib.ndt_hip_hcube_face_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.restype = C.c_int64
-    lib.ndt_hip_hcube_face_tree.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.ndt_hip_hcube_face_tree.restype = C.c_int64
+    if hasattr(lib, "ndt_hip_hcube_face_tree"):     # (absent from round 3's library, which profiles/ab_libs.sh still loads to compare builds)
+        lib.ndt_hip_hcube_face_tree.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ndt_hip_hcube_face_tree.restype = C.c_int64
     lib.ndt_hip_render_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_render_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

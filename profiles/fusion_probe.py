@@ -1,5 +1,5 @@
 """Frame time with and without the first trace launch making its own primaries (option fuse_primaries), per-bounce kernels.
-usage: python profiles/fusion_probe.py [WxH] [shard] [--opt=name]   (default option: fuse_primaries)"""
+usage: python profiles/fusion_probe.py [WxH] [shard] [--opt=name]   (default option: fuse_primaries; --auto: the default pipeline choice; --set=name=value: other options)"""
 import os
 import sys
 import time
@@ -18,7 +18,10 @@ for scene, depth in (("c3_random4d", 4), ("c2_balls4d", 4), ("c1_hypercube3d", 1
     fs = load_scene("tests/golden/%s.ndtscene.gz" % scene)
     g = NdtHip(0)
     g.upload_scene(fs)
-    g.set_option("pipeline", 1)
+    if "--auto" not in sys.argv:
+        g.set_option("pipeline", 1)
+    for kv in [a[6:] for a in sys.argv[1:] if a.startswith("--set=")]:
+        g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for fuse in (0, 1, 0, 1):
         g.set_option(opt, fuse)
         for _ in range(3):
