@@ -61,7 +61,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ctx->device = device;
     {
         // the environment is read here, once: nothing on the render or upload path looks at it
-        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "face_tree", "item_sets", "batch_cull", "gate_prepass", "gate_prepass_below", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "fuse_primaries", "shade_pair", "debug_levels",
+        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "face_tree", "item_sets", "gate_prepass", "gate_prepass_below", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "fuse_primaries", "shade_pair", "debug_levels",
                                              "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
         if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
@@ -146,7 +146,6 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
     else if (!strcmp(name, "face_tree")) ctx->face_tree = on;
     else if (!strcmp(name, "item_sets")) ctx->item_sets = on;
     else if (!strcmp(name, "item_boxes")) ctx->item_boxes = on;
-    else if (!strcmp(name, "batch_cull")) ctx->batch_cull = on;
     else if (!strcmp(name, "gate_prepass_below")) ctx->gate_prepass_below = value;
     else if (!strcmp(name, "gate_prepass")) ctx->gate_prepass = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "sample_seed")) ctx->sample_seed = value;
@@ -282,9 +281,7 @@ extern "C" int ndt_hip_trace_rays(ndt_hip_ctx *ctx, int64_t n_rays, const double
     HIP_TRY(hipMemsetAsync(ws.counters + NDT_CNT_QUEUE, 0, NDT_QUEUE_INTS * sizeof(int), s));
     tj.publish_level = -1;
     coop_setup(ctx, tj, nullptr);
-    SceneDesc sd_api = ctx->sd;         // (the batch cull also for these batches: arbitrary rays, usually no cone worth fitting)
-    sd_api.batch_cull = (ctx->batch_cull && ctx->tier == 0 && ctx->sd.mask_words == 1) ? 1 : 0;
-    ctx->kt->trace(s, ctx->d_blob, sd_api, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
+    ctx->kt->trace(s, ctx->d_blob, ctx->sd, ws, tj, ctx->tier, ctx->sd.mask_words, nullptr, nullptr);
     ctx->kt->hitpoints(s, ctx->d_blob, ctx->sd, ws.ray_o, ws.ray_v, ws.cap, ws.hit_prim, ws.hit_p, ws.hit_n, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(obj, ws.hit_obj, cnt * sizeof(int), hipMemcpyDeviceToHost, s));

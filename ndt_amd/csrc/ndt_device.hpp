@@ -69,7 +69,6 @@ struct SceneDesc {
     // item boxes (global-memory tier): one orthonormal frame, N x axis[N], and per item N x { centre, half extent }
     int off_oframe, off_obox;      // off_obox == 0: none.  An item's slabs are stored thinnest first ...
     int off_oord;                  // ... one word per item: the frame axis of its j-th slab in bits 4j .. 4j+3
-    int batch_cull;                // item sets: every batch fits a cone to its rays and drops the items whose sphere stays clear of it (batch_dead_items)
 };
 
 // ------------------------------------------------------------------ random streams
@@ -1515,7 +1514,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 done = true;
             } else {
                 mask.clear(sd.mask_words);
-                // item sets: the items no ray of this batch can pass the gate of (batch_dead_items) count as visited from the start
+                // item sets: items the caller knows no ray of this batch can pass the gate of count as visited from the start
                 if (BITS) mask.w[0] |= pre_dead;
                 if (BITS && sd.gate_bits != 0ull) {
                     // Gate prepass (experiment).  The gate of bounding.c:34-85 has a part that does not depend on min_dist: the
@@ -1926,104 +1925,6 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             out_prim = l_prim;
         }
     }
-}
-
-// ------------------------------------------------------------------ batch cull (item sets)
-//
-// The 64 rays of a batch are neighbours: the primaries of an 8x8 tile leave one eye, the shadow rays of a light's segment
-// leave the light (apply_lights casts them FROM the light, ndt.c:211) towards neighbouring hit points.  They fit a narrow
-// cone, and a bounding sphere that stays clear of the cone fails the gate of every one of them (bounding.c:60-85: the ray's
-// line misses the sphere, or the sphere lies behind the ray) -- whenever a scan reaches that item, all it does is get its
-// visit mark.  So once per batch the wavefront fits the cone (apex: the rays' common origin, or the mean origin with the
-// spheres grown by the origins' spread; axis: the mean direction; half angle: the widest ray) and lane i tests item i's
-// sphere against it: the items that stay clear are marked visited for the whole batch before the walk -- the rule of the gate
-// prepass, at a few instructions a ray instead of 34 an item a ray.  Leaf sets and node sets lose those items, subtrees that
-// hold nothing else are not entered, and a tile of sky is traced in one tree step.  Conservative by construction (angles
-// compared through cosines with a margin of 1e-9, a million times the rounding of the gate's own arithmetic): the answers
-// cannot change, and tests/test_gpu_parity.py checks that they do not.
-NDT_DEV double lane_get(double x, int l);
-NDT_DEV double wave_sum_d(double x)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
-}
-NDT_DEV double wave_min_d(double x)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const double y = __shfl_xor(x, d, 64);
-        x = y < x ? y : x;
-    }
-    return x;
-}
-// every lane of the wavefront calls; `live`: this lane has a ray.  Returns the items (bit i = item i) no ray of the batch can
-// pass the gate of.  Item-set scenes (at most 64 items).
-template <int N>
-NDT_DEV unsigned long long batch_dead_items(const double *blob, const SceneDesc &sd, const double (&o)[N], const double (&v)[N], const bool live)
-{
-    const unsigned long long lv = __ballot(live);
-    if (lv == 0ull) return 0ull;
-    const int n_live = __popcll(lv), first = __ffsll((long long)lv) - 1;
-    const int lane = __lane_id();
-    // the apex: the common origin, or the mean origin and how far the origins lie from it
-    double apex[N];
-    bool same = true;
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-        apex[c] = lane_get(o[c], first);
-        same = same && o[c] == apex[c];
-    }
-    double rho = 0.0;
-    if (__ballot(live && !same) != 0ull) {
-        double d2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < N; ++c) apex[c] = wave_sum_d(live ? o[c] : 0.0) / (double)n_live;
-#pragma unroll
-        for (int c = 0; c < N; ++c) d2 += (o[c] - apex[c]) * (o[c] - apex[c]);
-        rho = sqrt(-wave_min_d(live ? -d2 : 0.0)) * (1.0 + 1e-9);
-    }
-    // the axis: the mean direction; the half angle: the ray that leans furthest from it
-    double a[N], a2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-        a[c] = wave_sum_d(live ? v[c] : 0.0);
-        a2 += a[c] * a[c];
-    }
-    if (!(a2 > 0.0625 * (double)n_live * (double)n_live)) return 0ull;      // rays all over the place: no cone worth fitting
-    const double inv_a = 1.0 / sqrt(a2);
-    double av = 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-        a[c] *= inv_a;
-        av += a[c] * v[c];
-    }
-    double cos_t = wave_min_d(live ? av : 1.0) - 1e-9;                      // (directions are unit vectors, vectNd_unitize)
-    if (cos_t > 1.0) cos_t = 1.0;
-    if (cos_t < -1.0) return 0ull;
-    const double sin_t = sqrt(1.0 - cos_t * cos_t);
-    // item `lane`: clear of the cone?
-    bool dead = false;
-    if (lane < sd.n_items && (blob_int(blob, sd.off_hdr + 2 * lane, 0) & NDT_F_GATE)) {
-        const int b = sd.off_bs + lane * (N + 2);
-        double w[N], d2 = 0.0, aw = 0.0;
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-            w[c] = blob[b + c] - apex[c];
-            d2 += w[c] * w[c];
-            aw += a[c] * w[c];
-        }
-        const double big_r = blob[b + N] + rho;                             // (an origin rho away sees the sphere at most rho nearer)
-        if (big_r > 0.0 && d2 > big_r * big_r * (1.0 + 1e-9)) {
-            const double d = sqrt(d2);
-            const double sin_a = big_r / d, cos_a = sqrt(1.0 - sin_a * sin_a);
-            // the sphere's centre lies at angle phi from the axis and the sphere spans alpha around it: clear of the cone iff
-            // phi > theta + alpha (with theta + alpha < pi)
-            const double sin_ta = sin_t * cos_a + cos_t * sin_a, cos_ta = cos_t * cos_a - sin_t * sin_a;
-            if (sin_ta > 1e-9 && aw / d < cos_ta - 1e-9) dead = true;
-        }
-    }
-    return __ballot(dead);
 }
 
 // ------------------------------------------------------------------ cooperative trace: ONE ray, a whole wavefront
