@@ -80,7 +80,7 @@ def committed_profile(workload, width, height):
     rule, checked on k_finish_pixels), its FP64-issue figures, and the hash of the library it was measured on.  Counters
     cannot be read from inside a run; a profile of ANOTHER build is not quoted (traffic stays null, "profile_stale")."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r03_profile_%s_%dp.json" % (workload, height))
+    path = os.path.join(ROOT, "profiles", "r04_profile_%s_%dp.json" % (workload, height))
     if width != 1920 or not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -372,7 +372,7 @@ def main():
                 roofline["secondary"] = {"bound": "fp64_valu_issue", "frac": prof["fp64_valu_issue_frac"],
                                          "lane_util": prof.get("lane_utilisation"), "salu_per_valu": prof.get("salu_per_valu"),
                                          "wait_frac_of_wave_cycles": prof.get("wait_frac_of_wave_cycles"),
-                                         "source": "profiles/r03_profile_%s_%dp.json" % (args.workload, height)}
+                                         "source": "profiles/r04_profile_%s_%dp.json" % (args.workload, height)}
         line = {
             "metric": "Mray/s (primary+shadow+reflect) at 1920x1080",
             "value": total_traced / elapsed / 1e6,

@@ -280,6 +280,13 @@ template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
 }
 #endif
 
+NDT_DEV double lane_get(double x, int l)        // x of lane l (l: the same in every lane)
+{
+    const int ls = __builtin_amdgcn_readfirstlane(l);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), ls), hi = __builtin_amdgcn_readlane(__double2hiint(x), ls);
+    return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------ scene blob access
 
 // The blob pointer is either LDS or global; all reads go through these so that the
@@ -1139,7 +1146,8 @@ struct ClsLds {
 };
 // 64 entries, 64 x {param_off, words | m << 16}, 64 axis orders, 64 x 2N words (an item's box rows, or its bounding sphere when it has no
 // box), two records (2 header words + the sphere + par_words of parameters each)
-template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words); }
+// ... and the group's beam: per frame axis { u.o of the rays' common origin, the smallest and the largest 1 / (u.v), usable }
+template <int N> constexpr int cls_window_words(int par_words) { return 64 + 64 + 64 + 64 * 2 * N + 2 * (2 + N + 2 + par_words) + 4 * N; }
 /* sphere (N + 2 words) + parameters are fetched as two words per lane: 128 words a record (ndt_blob.hip:build_blob checks it per N) */
 
 NDT_DEV void cls_lds_sync()
@@ -1181,6 +1189,48 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
     if (mine && box_slot && !boxed) {
         ray_in_box_frame<N>(blob, sd, o, v, box_slot);
         boxed = true;
+    }
+    // The group's BEAM (round 4).  The rays that scan a leaf together are a tile's primaries or a light's shadow rays: one
+    // origin, neighbouring directions.  With one origin the slab arithmetic of item_box_meets is, per axis, a product of a
+    // number that is the same for all of them ((+-h - a), a = u.o - centre) and the ray's own 1 / (u.v) -- and a correctly
+    // rounded product is monotone in a factor, so over the group the ends of a slab's interval lie between their values at the
+    // smallest and at the largest 1 / (u.v) in the group.  An item whose box is missed by that envelope is missed by every ray
+    // of the group, exactly as each would compute it: lane i tests item i of the window against the envelope (one pass for 64
+    // items), and only the survivors -- a handful of a leaf's 60 .. 227 -- go through the loop in which every lane tests an
+    // item against its own ray.  Axes along which some ray runs parallel to the slab, or the reciprocals change sign, give no
+    // bound (left out: conservative); rays of several origins: no beam.
+    double *l_beam = l_par + 2 * par_stride;
+    bool beam = false;
+    if (box_slot) {
+        cls_lds_sync();
+        const unsigned long long grp = __ballot(mine);
+        const int first = __ffsll((long long)grp) - 1;
+        bool one_origin = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ndt_v2d pr;
+            pr.x = 0.0;
+            pr.y = 0.0;
+            if (mine) pr = *reinterpret_cast<const ndt_v2d *>(box_slot + k * 128);
+            const double x0 = lane_get(pr.x, first);
+            if (__ballot(mine && pr.x != x0) != 0ull) one_origin = false;
+            const bool parallel = __ballot(mine && pr.y == 0.0) != 0ull;
+            double lo = mine ? pr.y : NDT_DBL_MAX, hi = mine ? pr.y : -NDT_DBL_MAX;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const double l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if (lane == 0) {
+                l_beam[4 * k] = x0;
+                l_beam[4 * k + 1] = lo;
+                l_beam[4 * k + 2] = hi;
+                l_beam[4 * k + 3] = (!parallel && (lo > 0.0 || hi < 0.0)) ? 1.0 : 0.0;
+            }
+        }
+        beam = one_origin;
+        cls_lds_sync();
     }
     for (int base = w0; base < e0; base += 64) {
         if (__ballot(open) == 0ull) break;
@@ -1228,7 +1278,36 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
         // now (object.c:618-624; a superset, the gate is repeated at its moment below); and those any ray may
         unsigned long long want = 0ull, any = 0ull;
         if (__ballot(open) != 0ull) {
-            for (int k = 0; k < cnt; ++k) {
+            // the window's items the beam leaves: item `lane` against the group's envelope (boxed items; the others stay)
+            unsigned long long todo = (cnt < 64) ? ((1ull << cnt) - 1ull) : ~0ull;
+            if (beam) {
+                bool keep = true;
+                if (lane < cnt && (((int)(__double_as_longlong(l_ref[lane]) >> 32)) & NDT_F_OBOX)) {
+                    const unsigned long long ord = (unsigned long long)__double_as_longlong(l_ord[lane]);
+                    double t0 = 0.0, t1 = NDT_DBL_MAX;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const int axis = (int)((ord >> (4 * k)) & 15ull);
+                        const ndt_v2d box = *reinterpret_cast<const ndt_v2d *>(l_win + lane * 2 * N + 2 * k);
+                        const double x0 = l_beam[4 * axis], i0 = l_beam[4 * axis + 1], i1 = l_beam[4 * axis + 2];
+                        if (l_beam[4 * axis + 3] != 0.0) {
+                            const double a = x0 - box.x, h = box.y;
+                            const double p = -h - a, q = h - a;
+                            const double c1 = p * i0, c2 = p * i1, c3 = q * i0, c4 = q * i1;
+                            const double lo12 = c1 < c2 ? c1 : c2, lo34 = c3 < c4 ? c3 : c4;
+                            const double hi12 = c1 < c2 ? c2 : c1, hi34 = c3 < c4 ? c4 : c3;
+                            const double lo = lo12 < lo34 ? lo12 : lo34, hi = hi12 > hi34 ? hi12 : hi34;
+                            if (lo > t0) t0 = lo;
+                            if (hi < t1) t1 = hi;
+                        }
+                    }
+                    keep = t0 <= t1;
+                }
+                todo &= __ballot(keep);
+            }
+            while (todo != 0ull) {
+                const int k = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
                 const int flags = __builtin_amdgcn_readfirstlane((int)(__double_as_longlong(l_ref[k]) >> 32));
                 bool pass = open;
                 if (flags & NDT_F_OBOX) {
@@ -1947,12 +2026,6 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
 // Called with all 64 lanes active and the same ray in every lane.  Item-set scenes only (sd.mask_words == 1, sets in the
 // blob: sd.off_nset, sd.inf_bits).
 
-NDT_DEV double lane_get(double x, int l)        // x of lane l (l: the same in every lane)
-{
-    const int ls = __builtin_amdgcn_readfirstlane(l);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), ls), hi = __builtin_amdgcn_readlane(__double2hiint(x), ls);
-    return __hiloint2double(hi, lo);
-}
 // x with lane l's value replaced by val (val, l: the same in every lane)
 NDT_DEV int lane_put(int x, int val, int l) { return ((int)__lane_id() == l) ? val : x; }
 NDT_DEV double lane_put(double x, double val, int l) { return ((int)__lane_id() == l) ? val : x; }
