@@ -1492,11 +1492,11 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     NDT_STAMP(5);
 
     // results
+    // (`ret` of the infinite list is inf_obj >= 0, `lret` of the tree l_obj >= 0: a list returns a hit exactly when it accepted one,
+    // and the first hit a leaf returns is always taken -- lt starts at DBL_MAX)
     double t_inf = NDT_DBL_MAX;             // `t` of kd_tree_intersect, kd-tree.c:593
-    bool ret_inf = false;
     int inf_obj = -1, inf_prim = -1;
     double lt = NDT_DBL_MAX;                // `lt`, kd-tree.c:599
-    bool lret = false;
     int l_obj = -1, l_prim = -1;
 
     // traversal state
@@ -1505,8 +1505,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     int sp = 0;
     int node = 0;
     double ntl = 0, ntu = 0;
-    bool have_node = false, done = false;
-    bool root_pending = true;       // the root box has not been tested yet
+    // Where the lane stands, as ONE integer (round 4: every boolean that lives across these divergent loops is an exec mask in a
+    // scalar register pair, merged with three scalar instructions at every join -- the loops were more scalar than vector code):
+    //   0 a node to pop   1 a node to visit   2 a leaf's list to scan   3 finished   4 the root box to test   5 the infinite list to scan
+    int st = 4;
     bool boxed = false;             // this ray's projections on the scene's box frame are in its LDS slot (item boxes)
 
     // Item sets (MW == 1).  The reference scans a leaf's list in order and skips the items this ray has visited
@@ -1517,12 +1519,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
     constexpr bool BITS = (MW == 1);
     unsigned long long cand = 0ull;         // BITS: items of the current outer list still to be scanned
     // current list
-    bool have_list = false, list_is_inf = false;
     int sec = 0, pos = 0, end = 0;
     double min_dist = -1;                   // trace()'s min_dist for the current list
     int best_obj = -1, best_prim = -1;
     // nested (hcube) list
-    bool in_sub = false;
     int sub_i = 0, sub_end = 0, sub_owner = -1, sub_prim = -1;
     long long sub_live = -1;                // faces still to scan, bit 0 = the one at sub_i (all ones: every face; 0: sub_i
                                             // stands at the start of a chunk of 63 faces whose boxes are yet to be looked at)
@@ -1530,12 +1530,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
 
     if (!has_ray) {
         // (UNI wavefronts only: a lane without a ray that stays as a helper of the coherent leaf scan)
-        done = true;
-        root_pending = false;
+        st = 3;
     } else if (sd.n_inf > 0) {
         // infinite objects first, linear, unmasked (kd-tree.c:594)
-        have_list = true;
-        list_is_inf = true;
+        st = 5;
         if (BITS) {
             cand = sd.inf_bits;
         } else {
@@ -1561,8 +1559,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
             }
         }
         // ------------------------------------------------------------ phase T
-        if (!have_list && !done && root_pending) {
-            root_pending = false;
+        if (st == 4) {
             // aabb_intersect on the root box, kd-tree.c:84-127
             double tl = -NDT_DBL_MAX, tu = NDT_DBL_MAX;
             bool box = true;
@@ -1590,7 +1587,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 box = (tu >= -NDT_EPS) && (tl <= tu);
             }
             if (!box || sd.n_kd_nodes <= 0) {
-                done = true;
+                st = 3;
             } else {
                 mask.clear(sd.mask_words);
                 // item sets: items the caller knows no ray of this batch can pass the gate of count as visited from the start
@@ -1620,123 +1617,102 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 node = 0;
                 ntl = tl;
                 ntu = tu;
-                have_node = true;
+                st = 1;
             }
         }
-        // (one tree step as a lambda: NDT_T_STEPS of them per trip of the loop -- the loop-carried state is merged once per trip)
-        auto t_step = [&]() {
-            NDT_OCC(0);
-            bool visit = have_node;
-            if (!have_node) {
-                if (sp == 0) {
-                    done = true;
-                } else {
-                    --sp;
-                    int nf;
-                    double a;
-                    if (LSTACK) {
-                        // the entry names the parent; tp and the far child are recomputed from its record
-                        // with the operations of the push (same operands, same result)
-                        const int parent = ls.node[sp * ls.stride];
-                        ntu = ls.tu[sp * ls.stride];
-                        const ndt_v2d prec = blob_pair(blob, sd.off_kd + 2 * parent);
-                        const long long pw0 = __double_as_longlong(prec.x);
-                        const int pdim = (int)(pw0 & 0xffffffffll);
-                        const double pv_inv = inv_at(pdim);
-                        a = (prec.y - v_pick<N>(o, pdim)) * pv_inv;
-                        nf = (pv_inv < NDT_EPS2) ? parent + 1 : (int)(pw0 >> 32);
+        // The lane's place in the walk is ONE integer -- 0: a node to pop, 1: a node to visit, 2: a list to scan, 3: finished --
+        // not three booleans: the compiler carries a boolean that lives across a divergent loop as an exec mask in a scalar
+        // register pair and merges it at every join (the loop was 99 vector + 118 scalar instructions; with the integer 105 + 60,
+        // and the benchmark frame went 1.43 -> 1.35 ms: round 4).  The parallel-plane case of kd-tree.c:555-565 is gone: v_inv is
+        // clamped to +-1/EPS^2 when it is made (kd-tree.c:576-590; inv_of above), so `-INV_EPS2 <= v_inv_i <= INV_EPS2` always holds.
+        {
+            while (st < 2) {
+                NDT_OCC(0);
+                if (st == 0) {
+                    if (sp == 0) {
+                        st = 3;
                     } else {
-                        nf = st_node[sp];
-                        a = st_a[sp];
-                        ntu = st_tu[sp];
+                        --sp;
+                        double a;
+                        if (LSTACK) {
+                            // the entry names the parent; tp and the far child are recomputed from its record
+                            // with the operations of the push (same operands, same result)
+                            const int parent = ls.node[sp * ls.stride];
+                            ntu = ls.tu[sp * ls.stride];
+                            const ndt_v2d prec = blob_pair(blob, sd.off_kd + 2 * parent);
+                            const long long pw0 = __double_as_longlong(prec.x);
+                            const int pdim = (int)(pw0 & 0xffffffffll);
+                            const double pv_inv = inv_at(pdim);
+                            a = (prec.y - v_pick<N>(o, pdim)) * pv_inv;
+                            node = (pv_inv < NDT_EPS2) ? parent + 1 : (int)(pw0 >> 32);
+                        } else {
+                            node = st_node[sp];
+                            a = st_a[sp];
+                            ntu = st_tu[sp];
+                        }
+                        ntl = a - NDT_EPS;
+                        // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done; `tu < 0` (kd-tree.c:490)
+                        st = (lt > a && !(ntu < 0.0)) ? 1 : 0;
                     }
-                    node = nf & ~NDT_STACK_FLAG;
-                    ntl = (nf & NDT_STACK_FLAG) ? a : a - NDT_EPS;
-                    // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done
-                    visit = lt > a;
+                } else if (ntu < 0.0) {
+                    st = 0;                                             // kd-tree.c:490
                 }
-            }
-            have_node = false;
-            if (visit && !(ntu < 0.0)) {                 // kd-tree.c:490
-                NDT_COUNT(0);
-                const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
-                // BITS: the items below this node that the ray has not visited yet.  None left: nothing in this subtree can
-                // change the ray's state any more (its leaves would scan nothing), so the walk does not enter it.
-                unsigned long long below = ~0ull;
-                if (BITS) below = (unsigned long long)__double_as_longlong(blob[sd.off_nset + node]) & ~mask.w[0];
-                const long long w0 = __double_as_longlong(rec.x);
-                const int dim = (int)(w0 & 0xffffffffll);
-                if (BITS && below == 0ull) {
-                    // (subtree exhausted)
-                } else if (dim < 0) {
-                    // leaf: trace() over its items (kd-tree.c:497-519)
-                    const long long w1 = __double_as_longlong(rec.y);
-                    if (BITS) {
-                        have_list = true;
-                        list_is_inf = false;
-                        cand = below;
-                    } else {
-                        const int num = (int)(w1 >> 32);
-                        if (num > 0) {
-                            have_list = true;
-                            list_is_inf = false;
+                if (st == 1) {
+                    NDT_COUNT(0);
+                    const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
+                    // BITS: the items below this node that the ray has not visited yet.  None left: nothing in this subtree can
+                    // change the ray's state any more (its leaves would scan nothing), so the walk does not enter it.
+                    unsigned long long below = ~0ull;
+                    if (BITS) below = (unsigned long long)__double_as_longlong(blob[sd.off_nset + node]) & ~mask.w[0];
+                    const long long w0 = __double_as_longlong(rec.x);
+                    const int dim = (int)(w0 & 0xffffffffll);
+                    if (BITS && below == 0ull) {
+                        st = 0;                                         // (subtree exhausted)
+                    } else if (dim < 0) {
+                        // leaf: trace() over its items (kd-tree.c:497-519)
+                        if (BITS) {
+                            st = 2;
+                            cand = below;
+                        } else {
+                            const long long w1 = __double_as_longlong(rec.y);
+                            const int num = (int)(w1 >> 32);
+                            st = num > 0 ? 2 : 0;
                             sec = sd.off_leaf;
                             pos = (int)(w1 & 0xffffffffll);
                             end = pos + num;
                         }
-                    }
-                } else {
-                    const double boundary = rec.y;
-                    const double v_inv_i = inv_at(dim);
-                    const double o_i = v_pick<N>(o, dim);
-                    // preorder: the left child follows its parent; swap for negative directions
-                    const bool swap = v_inv_i < NDT_EPS2;
-                    const int left = node + 1, right = (int)(w0 >> 32);
-                    const int near = swap ? right : left, far = swap ? left : right;
-                    if (-NDT_INV_EPS2 <= v_inv_i && v_inv_i <= NDT_INV_EPS2) {
+                    } else {
+                        const double boundary = rec.y;
+                        const double v_inv_i = inv_at(dim);
+                        const double o_i = v_pick<N>(o, dim);
+                        // preorder: the left child follows its parent; swap for negative directions
+                        const bool swap = v_inv_i < NDT_EPS2;
+                        const int left = node + 1, right = (int)(w0 >> 32);
+                        const int near = swap ? right : left, far = swap ? left : right;
+                        // kd-tree.c:541-554, its three cases as selects.  `lt` only ever decreases, so testing `lt > tp` before
+                        // pushing the far child is safe; the test that counts is repeated at pop time.
                         const double tp = (boundary - o_i) * v_inv_i;
                         const bool alive = lt > ntl;
-                        // kd-tree.c:541-554.  `lt` only ever decreases, so testing `lt > tp` before
-                        // pushing the far child is safe; the test that counts is repeated at pop time.
-                        if (ntu < tp - NDT_EPS && alive) {
-                            node = near; have_node = true;              // near only, same interval
-                        } else if (ntl > tp + NDT_EPS && alive) {
-                            node = far; have_node = true;               // far only, same interval
-                        } else {
-                            if (lt > tp) {
-                                if (LSTACK) { ls.node[sp * ls.stride] = node; ls.tu[sp * ls.stride] = ntu; }
-                                else { st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; }
-                                ++sp;                                   // far: (tp-EPS, tu), gate tp
-                            }
-                            if (alive) { node = near; ntu = tp + NDT_EPS; have_node = true; }
+                        const bool near_only = ntu < tp - NDT_EPS && alive;             // near, same interval
+                        const bool far_only = !near_only && ntl > tp + NDT_EPS && alive; // far, same interval
+                        const bool both = !near_only && !far_only;
+                        if (both && lt > tp) {
+                            if (LSTACK) { ls.node[sp * ls.stride] = node; ls.tu[sp * ls.stride] = ntu; }
+                            else { st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; }
+                            ++sp;                                       // far: (tp-EPS, tu), gate tp
                         }
-                    } else {
-                        // plane parallel to the ray: unreachable for finite directions (|v_inv| <= 1/EPS^2
-                        // by construction), kept for fidelity with kd-tree.c:555-565
-                        if (o_i > boundary - NDT_EPS) {
-                            // (never taken: |v_inv| <= 1/EPS^2 by construction; the LDS stack has no form for this entry)
-                            if (!LSTACK) { st_node[sp] = far | NDT_STACK_FLAG; st_a[sp] = ntl; st_tu[sp] = ntu; ++sp; }
-                        }
-                        if (o_i < boundary + NDT_EPS && lt > ntl) { node = near; have_node = true; }
+                        const bool go_near = near_only || (both && alive);
+                        ntu = (both && alive) ? tp + NDT_EPS : ntu;     // near: (tl, tp+EPS)
+                        node = go_near ? near : far;
+                        st = (go_near || far_only) ? 1 : 0;
                     }
                 }
             }
-        };
-#ifndef NDT_T_STEPS
-#define NDT_T_STEPS 1
-#endif
-        while (!have_list && !done) {
-            t_step();
-#if NDT_T_STEPS >= 2
-            if (!have_list && !done) t_step();
-#endif
-#if NDT_T_STEPS >= 3
-            if (!have_list && !done) t_step();
-#endif
         }
         NDT_STAMP(0);
         // done.  (UNI: a lane whose ray is finished stays with the wavefront until every ray is -- it helps the others fetch
         // in the coherent leaf scan -- and sits out everything else)
+        const bool have_list = st == 2 || st == 5, list_is_inf = st == 5;
         if (UNI ? (__ballot(have_list) == 0ull) : !have_list) break;
 
         // ------------------------------------------------------------ phases G + I over the list
@@ -1783,13 +1759,16 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 }
             }
         }
-        while (list_open) {
+        // Where the lane stands in its list is ONE integer, as in the walk above (booleans that live across these loops cost a
+        // scalar register pair and three scalar instructions at every join): 0 scanning the list, 1 scanning an hcube's faces
+        // (the nested trace() of hcube.c:241), 2 / 3 a primitive of the list / a face to intersect, 4 the list is done.
+        int gs = list_open ? 0 : 4;
+        while (gs != 4) {
             // ---- phase G: advance to the next primitive that passes its gate
             int prim = -1;
-            bool scanning = true;
-            while (scanning) {
+            while (gs < 2) {
                 NDT_OCC(1);
-                if (in_sub && sub_live == 0) {
+                if (gs == 1 && sub_live == 0) {
                     // The hcube's faces from the chunk sub_i stands on: hull box, then the boxes of 63 faces at a time until
                     // the ray meets one (one call site for the first faces of an hcube and for its later chunks).  Nothing
                     // met: the nested trace() is over -- for an hcube just entered, before it began (its result: no hit).
@@ -1803,7 +1782,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                                              (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk, (oflags & NDT_F_FACETREE) != 0);
                     if (live == 0) {
                         // (an hcube just entered: it never began -- no result to apply, the scan goes on in this very step)
-                        if (fresh_hcube) in_sub = false;
+                        if (fresh_hcube) gs = 0;
                         else sub_i = sub_end;
                         sub_live = -1;
                     } else {
@@ -1812,10 +1791,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         sub_live = live >> skip;
                     }
                 }
-                if (in_sub && sub_i == sub_end) {
+                if (gs == 1 && sub_i == sub_end) {
                     // nested trace() finished: hcube.intersect returns (hcube.c:241-248),
                     // then the outer trace() applies its accept / break rules
-                    in_sub = false;
+                    gs = 0;
                     if (sub_min >= 0) {
                         const double dist = sub_min;    // == |o - res| of the accepted face
                         if (dist > NDT_EPS && (dist + NDT_EPS < min_dist || min_dist < 0)) {
@@ -1828,8 +1807,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             else end = pos;         // (not pos = end: pos - 1 stays the last item the scan looked at)
                         }
                     }
-                } else if (!in_sub && (BITS ? cand == 0ull : pos == end)) {
-                    scanning = false;       // list exhausted
+                } else if (gs == 0 && (BITS ? cand == 0ull : pos == end)) {
+                    gs = 4;                 // list exhausted
                 } else {
                     // one item of the list: visit mark, gate, and what passing the gate leads to
                     auto scan_item = [&](const int id, const int flags, const bool masked) {
@@ -1846,8 +1825,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                         if (fresh) {
                             // vect_object_intersect's gate (object.c:618-624), for composites too
-                            const double gate_min = in_sub ? sub_min : min_dist;
-                            if (in_sub) NDT_COUNT(1); else NDT_COUNT(3);
+                            const double gate_min = (gs == 1) ? sub_min : min_dist;
+                            if (gs == 1) NDT_COUNT(1); else NDT_COUNT(3);
                             bool gate = true;
                             if (flags & NDT_F_GATE) gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
                             if (gate) {
@@ -1856,7 +1835,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                                     // (which of its faces are scanned is found at the top of the scanning loop: sub_live == 0)
                                     const int first = blob_int(blob, sd.off_hdr + 2 * id + 1, 0);
                                     const int nf = blob_int(blob, sd.off_hdr + 2 * id + 1, 1);
-                                    in_sub = true;
+                                    gs = 1;
                                     sub_owner = id;
                                     sub_i = first;
                                     sub_end = first + nf;
@@ -1865,8 +1844,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                                     sub_prim = -1;
                                 } else {
                                     prim = id;
-                                    scanning = false;
-                                    if (in_sub) NDT_COUNT(2); else NDT_COUNT(4);
+                                    if (gs == 1) NDT_COUNT(2); else NDT_COUNT(4);
+                                    gs += 2;
                                 }
                             }
                         }
@@ -1879,7 +1858,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     if (UNI && !BITS) {
                         const int w = sec + pos;
                         w_u = __builtin_amdgcn_readfirstlane(w);
-                        together = __ballot(in_sub || w != w_u) == 0ull;
+                        together = __ballot(gs == 1 || w != w_u) == 0ull;
                     }
                     if (together) {
                         int id, flags;
@@ -1888,6 +1867,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         scan_item(id, flags, !list_is_inf);
                     } else {
                         int id, flags;
+                        const bool in_sub = gs == 1;
                         if (BITS && !in_sub) {
                             const unsigned long long bit = cand & (0ull - cand);        // the lowest item of the set
                             id = __ffsll((long long)cand) - 1;
@@ -1920,9 +1900,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 }
             }
             NDT_STAMP(1);
-            if (prim < 0) {
-                list_open = false;
-            } else {
+            if (gs != 4) {
                 // ---- phase I: intersect
                 NDT_OCC(2);
 #ifdef NDT_PHASE_TIMING
@@ -1947,7 +1925,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 if (ok) {
                     NDT_COUNT(5);
                     const double dist = v_dist<N>(o, res);          // object.c:721
-                    if (in_sub) {
+                    if (gs == 3) {
                         // inner trace(): dist_limit = -1, no mask (hcube.c:241)
                         if (dist > NDT_EPS && (dist + NDT_EPS < sub_min || sub_min < 0)) {
                             sub_min = dist;
@@ -1965,41 +1943,39 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                     }
                 }
+                gs -= 2;            // back to the list (2 -> 0) or to the hcube's faces (3 -> 1)
                 NDT_STAMP(2);
             }
         }
 
         // ---- list finished: what trace() returns to its caller
         NDT_STAMP(3);
-        const bool had_list = have_list;
-        have_list = false;
-        if (MW == 0 && had_list && !list_is_inf && !scanned_together) {
+        if (MW == 0 && st == 2 && !scanned_together) {
             // the leaf's ordinal (its record, which `node` still names) and the last item the scan looked at
             int last, flags_;
             blob_ref(blob, sec + pos - 1, last, flags_);
             mask.end_leaf(blob_int(blob, sd.off_kd + 2 * node, 1), last);
         }
-        if (!had_list) {
-            // (a finished lane of a UNI wavefront)
-        } else if (list_is_inf) {
-            ret_inf = min_dist >= 0;
+        if (st == 5) {
             if (min_dist > NDT_EPS) t_inf = min_dist;           // object.c:736
             inf_obj = best_obj;
             inf_prim = best_prim;
-        } else if (min_dist >= 0) {
-            lret = true;
-            if (min_dist < lt) {                                // `ret && t < *t_ptr`, kd-tree.c:506
+            st = 4;                                             // next: the tree
+        } else if (st == 2) {
+            if (min_dist >= 0 && min_dist < lt) {               // `ret && t < *t_ptr`, kd-tree.c:506
                 lt = min_dist;
                 l_obj = best_obj;
                 l_prim = best_prim;
             }
+            st = 0;                                             // next: what the stack holds
         }
+        // (st == 3 here: a finished lane of a UNI wavefront)
     }
 
     out_obj = inf_obj;
     out_prim = inf_prim;
-    if (lret) {
-        if (!ret_inf || (lt > NDT_EPS && lt + NDT_EPS < t_inf)) {   // kd-tree.c:612
+    if (l_obj >= 0) {
+        if (inf_obj < 0 || (lt > NDT_EPS && lt + NDT_EPS < t_inf)) {   // kd-tree.c:612
             out_obj = l_obj;
             out_prim = l_prim;
         }

@@ -323,7 +323,10 @@ __global__ void __launch_bounds__(256) k_resolve(const double *blob, SceneDesc s
 // (the pixel itself: ndt_finish.hpp)
 // resolve0: the bottom-up combine of the primaries' own bounce (the last k_resolve) happens here, in the thread that then
 // finishes the pixel: one launch less at the end of a frame
-__global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
+#ifndef NDT_FINISH_BLOCK
+#define NDT_FINISH_BLOCK 256
+#endif
+__global__ void __launch_bounds__(NDT_FINISH_BLOCK) k_finish_pixels(const double *blob, SceneDesc sd, Workspace ws, RenderGeom rg, int N_,
                                                        double *rgba, double *depth_out, int resolve0)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(256) k_finish_pixels(const double *blob, Scene
     // wavefront sum, then one atomic per wavefront spread over 64 cache lines (a single word
     // saturates near 90 atomics/us, and there are 32k wavefronts at 1080p)
     for (int d = 32; d > 0; d >>= 1) weighted += __shfl_down(weighted, d, 64);
-    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), weighted);
+    if ((threadIdx.x & 63) == 0 && weighted) atomicAdd(ws.ref_rays + 8 * ((blockIdx.x * (NDT_FINISH_BLOCK / 64) + (threadIdx.x >> 6)) & 63), weighted);
 }
 
 // max_optic_depth <= 0: get_ray_color returns black without tracing (ndt.c:340)
@@ -517,7 +520,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             if (!sa.fused) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
             kt->frame_stream(s, ctx->d_blob, sd_pass, ws, rg, sa, ctx->tier, ctx->sd.mask_words, ev_k0, ev_k1);
             if (!sa.fused)
-                hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
+                hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + NDT_FINISH_BLOCK - 1) / NDT_FINISH_BLOCK)), dim3(NDT_FINISH_BLOCK), 0, s, ctx->d_blob, sd_pass, ws,
                                    rg, ctx->dims, (double *)d_rgba, (double *)d_depth, 0);
             if (prof)
                 hipExtLaunchKernelGGL(k_stream_done, dim3(1), dim3(64), 0, s, nullptr, ev_end, 0u, ws, sa, ctx->d_done, tag);
@@ -784,7 +787,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, ctx->d_blob, sd_pass, ws, rg.specular, b);
             }
         }
-        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + 255) / 256)), dim3(256), 0, s, ctx->d_blob, sd_pass, ws,
+        hipLaunchKernelGGL(k_finish_pixels, dim3((unsigned)((rg.n_primary + NDT_FINISH_BLOCK - 1) / NDT_FINISH_BLOCK)), dim3(NDT_FINISH_BLOCK), 0, s, ctx->d_blob, sd_pass, ws,
                            rg, ctx->dims, (double *)d_rgba, (double *)d_depth, n_run >= 1 ? 1 : 0);
         const StreamCtl *sctl = streamed ? sa.ctl : nullptr;
         if (prof)
