@@ -161,7 +161,7 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
         if (value < 0 || value > 2) return fail(NDT_E_INVALID, "multi_path %lld", (long long)value);
         ctx->multi_path = (int)value;
     } else if (!strcmp(name, "stream_fused")) ctx->stream_fused = on;
-    else if (!strcmp(name, "fuse_primaries")) ctx->fuse_primaries = on;
+    else if (!strcmp(name, "fuse_primaries")) ctx->fuse_primaries = value < 0 ? -1 : on ? 1 : 0;
     else if (!strcmp(name, "shade_pair")) ctx->shade_pair = on;
     else if (!strcmp(name, "debug_levels")) ctx->debug_levels = on;
     else if (!strcmp(name, "exit_probe")) ctx->exit_probe = on;

@@ -85,7 +85,10 @@ struct ndt_hip_ctx {
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
     bool face_tree = true;          // hcubes of more than 63 faces: a hierarchy over the face boxes (ndt_device.hpp:hull_faces)
-    bool fuse_primaries = true;     // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary)
+    // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary; k_trace's PRIM variant).  -1: from 6-D on
+    // (measured, 1080p, on / off: 6-D 1.308 / 1.331 ms, 8-D 3.249 / 3.303; 4-D equal; 3-D 0.593 / 0.581 -- the variant spills more
+    // than the plain kernel, which only the saved 2N doubles a ray written and read back pay for), 0 never, 1 always
+    int fuse_primaries = -1;
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)
     // item sets: the min_dist-free part of every gate before the walk (ndt_device.hpp:trace_kd).  0 never, 1 always, 2 (default)

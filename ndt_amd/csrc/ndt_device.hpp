@@ -1182,7 +1182,9 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
     sd_par.off_hdr = 0;
     sd_par.off_bs = 2;
     sd_par.off_params = 2 + N + 2;
-    bool open = mine;           // still scanning (object.c:730 ends a scan early)
+    // still scanning (object.c:730 ends a scan early).  An integer, not a boolean: it lives across the loops below, and a boolean that
+    // does is an exec mask in a scalar register pair, merged at every join (ndt_device.hpp:trace_kd, the lane's place as `st`)
+    int open = mine ? 1 : 0;
     min_dist = -1;
     best = -1;
     last = -1;
@@ -1233,7 +1235,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
         cls_lds_sync();
     }
     for (int base = w0; base < e0; base += 64) {
-        if (__ballot(open) == 0ull) break;
+        if (__ballot(open != 0) == 0ull) break;
         const int cnt = (e0 - base < 64) ? e0 - base : 64;
         // ---- the window: entry, header and box (or sphere) of the next `cnt` items, one per lane
         if (lane < cnt) {
@@ -1277,7 +1279,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
         // ---- the items this ray may have to intersect: its box, or else its sphere gate with the min_dist the ray has
         // now (object.c:618-624; a superset, the gate is repeated at its moment below); and those any ray may
         unsigned long long want = 0ull, any = 0ull;
-        if (__ballot(open) != 0ull) {
+        if (__ballot(open != 0) != 0ull) {
             // the window's items the beam leaves: item `lane` against the group's envelope (boxed items; the others stay)
             unsigned long long todo = (cnt < 64) ? ((1ull << cnt) - 1ull) : ~0ull;
             if (beam) {
@@ -1309,7 +1311,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
                 const int k = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
                 const int flags = __builtin_amdgcn_readfirstlane((int)(__double_as_longlong(l_ref[k]) >> 32));
-                bool pass = open;
+                bool pass = open != 0;
                 if (flags & NDT_F_OBOX) {
                     if (open) pass = item_box_meets<N>(l_win, sd_win, k, box_slot);
                 } else if (flags & NDT_F_GATE) {
@@ -1370,7 +1372,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
             const int id = __builtin_amdgcn_readfirstlane((int)(rbits & 0xffffffffll));
             const int flags = __builtin_amdgcn_readfirstlane((int)(rbits >> 32));
             const double *rec = l_par + cur * par_stride;
-            bool pass = open && ((want >> k) & 1ull);
+            bool pass = open != 0 && ((want >> k) & 1ull);
             if ((flags & NDT_F_GATE) && pass) pass = bsphere_gate<N>(rec, sd_par, 0, o, v, min_dist);      // the gate, at its moment
             if (pass) {
                 double res[N], nrm[N];
@@ -1381,7 +1383,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
                         best = id;
                     }
                     if (dist_limit == 0.0 || dist < dist_limit) {                                // object.c:730
-                        open = false;
+                        open = 0;
                         last = id;          // the scan ends here: the last item it looked at
                     }
                 }
@@ -1389,7 +1391,7 @@ NDT_DEV void cls_scan(const double *blob, const SceneDesc &sd, const VisitMask<M
             cur ^= 1;
             if (any != 0ull) put(l_par + cur * par_stride, n_flags, n_words, n_m, t0, t1);
             cls_lds_sync();
-            if (__ballot(open) == 0ull) any = 0ull;
+            if (__ballot(open != 0) == 0ull) any = 0ull;
         }
         cls_lds_sync();
         NDT_STAMP(2);

@@ -616,8 +616,9 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         int queue_slot = 0;
         int launches = 0;
+        const bool fuse_primaries = (ctx->fuse_primaries < 0 ? ctx->dims >= 6 : ctx->fuse_primaries != 0) && !ctx->coop;
         // (no k_primary: the first trace launch makes the primaries it traces, TraceJob::make_primaries)
-        if (!ctx->fuse_primaries || ctx->coop) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
+        if (!fuse_primaries) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {
             tj.queue = ws.counters + NDT_CNT_QUEUE + (queue_slot++) * NDT_QUEUE_INTS;
             const bool exit_probe = ctx->exit_probe;
@@ -642,7 +643,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
             tj.dense.valid = ws.depth_left; tj.dense.out_obj = ws.hit_obj; tj.dense.out_prim = ws.hit_prim;
             tj.begin = 0; tj.count = rg.n_primary; tj.levels = nullptr;
             tj.publish_level = -1;
-            if (ctx->fuse_primaries && !ctx->coop) {
+            if (fuse_primaries) {
                 tj.make_primaries = 1;
                 tj.rg = rg;
             }
