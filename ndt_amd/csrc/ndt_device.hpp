@@ -267,6 +267,7 @@ template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
 #else
 template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
 {
+#ifdef NDT_PICK_COPY
     double e0 = a[0];
     asm volatile("" : "+v"(e0));
     double r = e0;
@@ -277,6 +278,18 @@ template <int N> NDT_DEV double v_pick(const double (&a)[N], int i)
         r = (i == k) ? e : r;
     }
     return r;
+#else
+    // (the RESULT of every select is made opaque, not its operands: an opaque operand is a copy of a[k] -- a[k] stays live -- and
+    // a pick cost N v_mov_b64 on top of its selects)
+    double r = a[0];
+    asm volatile("" : "+v"(r));
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+        r = (i == k) ? a[k] : r;
+        asm volatile("" : "+v"(r));
+    }
+    return r;
+#endif
 }
 #endif
 
@@ -704,15 +717,14 @@ NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, cons
     blob_vec<N>(blob, b, c);
     v_sub<N>(o, c, oc);
     double oc_len2 = v_dot<N>(oc, oc);
-    if (min_dist > 0) {
-        double min_dist_r = min_dist + blob[b + N];
-        if (oc_len2 > min_dist_r * min_dist_r) return false;
-    }
+    // (one verdict from all the comparisons, & and | instead of early returns: a return in the middle is a divergent branch,
+    // and what it skips -- one dot product -- costs less than the branch)
+    const double min_dist_r = min_dist + blob[b + N];
+    const bool too_far = (min_dist > 0) & (oc_len2 > min_dist_r * min_dist_r);
     double voc = v_dot<N>(v, oc);
     double voc2 = voc * voc;
     double desc = voc2 - oc_len2 + blob[b + N + 1];
-    if (desc < 0.0 || (voc > 0.0 && voc2 > desc)) return false;
-    return true;
+    return !(too_far | (desc < 0.0) | ((voc > 0.0) & (voc2 > desc)));
 }
 
 // Ray (t >= 0) against the hull box of an hcube: N slabs { axis[N], centre, half extent }.
@@ -1634,13 +1646,14 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     if (sp == 0) {
                         st = 3;
                     } else {
-                        --sp;
+                        // (LDS stack: sp counts in entries' distance, ls.stride -- no multiplication per push and pop)
+                        sp -= LSTACK ? ls.stride : 1;
                         double a;
                         if (LSTACK) {
                             // the entry names the parent; tp and the far child are recomputed from its record
                             // with the operations of the push (same operands, same result)
-                            const int parent = ls.node[sp * ls.stride];
-                            ntu = ls.tu[sp * ls.stride];
+                            const int parent = ls.node[sp];
+                            ntu = ls.tu[sp];
                             const ndt_v2d prec = blob_pair(blob, sd.off_kd + 2 * parent);
                             const long long pw0 = __double_as_longlong(prec.x);
                             const int pdim = (int)(pw0 & 0xffffffffll);
@@ -1654,7 +1667,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         }
                         ntl = a - NDT_EPS;
                         // `*t_ptr > tp` (kd-tree.c:552), evaluated now that the near subtree is done; `tu < 0` (kd-tree.c:490)
-                        st = (lt > a && !(ntu < 0.0)) ? 1 : 0;
+                        st = ((lt > a) & !(ntu < 0.0)) ? 1 : 0;
                     }
                 } else if (ntu < 0.0) {
                     st = 0;                                             // kd-tree.c:490
@@ -1693,20 +1706,21 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         const int near = swap ? right : left, far = swap ? left : right;
                         // kd-tree.c:541-554, its three cases as selects.  `lt` only ever decreases, so testing `lt > tp` before
                         // pushing the far child is safe; the test that counts is repeated at pop time.
+                        // (& and |, not && and ||: a short-circuit is a branch, and every comparison here is cheap)
                         const double tp = (boundary - o_i) * v_inv_i;
                         const bool alive = lt > ntl;
-                        const bool near_only = ntu < tp - NDT_EPS && alive;             // near, same interval
-                        const bool far_only = !near_only && ntl > tp + NDT_EPS && alive; // far, same interval
-                        const bool both = !near_only && !far_only;
-                        if (both && lt > tp) {
-                            if (LSTACK) { ls.node[sp * ls.stride] = node; ls.tu[sp * ls.stride] = ntu; }
+                        const bool near_only = (ntu < tp - NDT_EPS) & alive;                // near, same interval
+                        const bool far_only = !near_only & (ntl > tp + NDT_EPS) & alive;    // far, same interval
+                        const bool both = !near_only & !far_only;
+                        if (both & (lt > tp)) {
+                            if (LSTACK) { ls.node[sp] = node; ls.tu[sp] = ntu; }
                             else { st_node[sp] = far; st_a[sp] = tp; st_tu[sp] = ntu; }
-                            ++sp;                                       // far: (tp-EPS, tu), gate tp
+                            sp += LSTACK ? ls.stride : 1;               // far: (tp-EPS, tu), gate tp
                         }
-                        const bool go_near = near_only || (both && alive);
-                        ntu = (both && alive) ? tp + NDT_EPS : ntu;     // near: (tl, tp+EPS)
+                        const bool go_near = near_only | (both & alive);
+                        ntu = (both & alive) ? tp + NDT_EPS : ntu;      // near: (tl, tp+EPS)
                         node = go_near ? near : far;
-                        st = (go_near || far_only) ? 1 : 0;
+                        st = (go_near | far_only) ? 1 : 0;
                     }
                 }
             }
