@@ -1300,8 +1300,8 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
                 cr += hit_r * lr_;
                 cg += hit_g * lg_;
                 cb += hit_b * lb_;
-                continue;
-            }
+            } else {
+            // (if / else and one `lit`, no `continue`: every early continue of a divergent loop is a flag the compiler carries round it)
             const int seg = __popcll(~ambient & ((1ull << li) - 1ull));         // its segment of the shadow queue
             const long long slot = (long long)seg * lr.seg_stride + ws.sh_idx[(long long)seg * ws.cap + g];
             int type;
@@ -1312,16 +1312,20 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
             const int sobj = ws.sobj[slot];
             const int sprim = ws.sprim[slot];
             ++n_shadow;
+            bool lit;
             if (type == NDT_LIGHT_DIRECTIONAL_) {
-                if (sobj >= 0) continue;                    // anything at all shadows it, ndt.c:246
+                lit = sobj < 0;                             // anything at all shadows it, ndt.c:246
                 v_copy<N>(light_hit_normal, nrm);           // ndt.c:252-254
             } else {
-                if (sobj != obj) continue;                  // ndt.c:217
-                double light_hit[N];
-                isect_full(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
-                const double dist = v_dist<N>(hit, light_hit);
-                if (dist > NDT_EPS) continue;               // ndt.c:225
+                lit = sobj == obj;                          // ndt.c:217
+                if (lit) {
+                    double light_hit[N];
+                    isect_full(blob, &sd, sprim, so, light_vec, light_hit, light_hit_normal);
+                    const double dist = v_dist<N>(hit, light_hit);
+                    lit = !(dist > NDT_EPS);                // ndt.c:225
+                }
             }
+            if (lit) {
             double angle = v_angle<N>(nrm, light_vec);      // ndt.c:263
             if (angle > NDT_PI / 2.0) angle = NDT_PI - angle;
             const double light_scale = nd_cos(angle) / ss.ldist2;
@@ -1344,6 +1348,8 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
                 cr += hitr_r * lr_ / max_light * rvn;
                 cg += hitr_g * lg_ / max_light * rvn;
                 cb += hitr_b * lb_ / max_light * rvn;
+            }
+            }
             }
         }
         if (resolve_here) {
