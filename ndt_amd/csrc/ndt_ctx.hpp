@@ -85,9 +85,10 @@ struct ndt_hip_ctx {
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
     bool face_tree = true;          // hcubes of more than 63 faces: a hierarchy over the face boxes (ndt_device.hpp:hull_faces)
-    // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary; k_trace's PRIM variant).  -1: from 6-D on
-    // (measured, 1080p, on / off: 6-D 1.308 / 1.331 ms, 8-D 3.249 / 3.303; 4-D equal; 3-D 0.593 / 0.581 -- the variant spills more
-    // than the plain kernel, which only the saved 2N doubles a ray written and read back pay for), 0 never, 1 always
+    // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary; k_trace's PRIM variant, planar camera).
+    // -1: from 4-D on (measured, 1080p, on / off: benchmark frame 1.297 / 1.304 ms, balls 0.814 / 0.821, 6-D 1.298 / 1.326, 8-D 3.25 / 3.28;
+    // 3-D 0.592 / 0.582 -- the variant spills a little more than the plain kernel, which the 2N doubles a ray it does not write and
+    // read back pay for from N = 4 on), 0 never, 1 always
     int fuse_primaries = -1;
     bool stream_fused = true;       // frame kernel: makes its primaries and writes its pixels itself (no k_primary / k_finish_pixels)
     bool item_sets = true;          // scenes of up to 64 items: leaf records carry item sets (ndt_blob.hip:build_blob)

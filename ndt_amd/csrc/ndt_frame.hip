@@ -616,7 +616,8 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
         }
         int queue_slot = 0;
         int launches = 0;
-        const bool fuse_primaries = (ctx->fuse_primaries < 0 ? ctx->dims >= 6 : ctx->fuse_primaries != 0) && !ctx->coop;
+        // (the variant is built for the planar camera: VR and panorama frames take k_primary)
+        const bool fuse_primaries = (ctx->fuse_primaries < 0 ? ctx->dims >= 4 : ctx->fuse_primaries != 0) && !ctx->coop && ctx->cam_type == 0;
         // (no k_primary: the first trace launch makes the primaries it traces, TraceJob::make_primaries)
         if (!fuse_primaries) kt->primary(s, ctx->d_blob, sd_pass, ws, rg);
         auto traced = [&](TraceJob &tj, const std::string &what) -> int {

@@ -106,7 +106,9 @@ template <bool COH> NDT_DEV void prim_stu(unsigned long long *p, unsigned long l
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
-template <bool COH>
+// PLANAR: the caller knows the camera is CAMERA_NORMAL (the trace kernel's PRIM variant: without the VR / panorama code the
+// variant spills no more than the plain kernel)
+template <bool COH, bool PLANAR = false>
 NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspace &ws, const RenderGeom &rg, long long g, double (&pos)[N],
                           double (&look)[N])
 {
@@ -165,8 +167,8 @@ NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspa
     blob_vec<N>(blob, sd.off_cam, pos);
     const double focal = blob[sd.off_cam + 4 * N];
     const int ext = sd.off_cam + 4 * N + 8;                     // type, hFov, vFov, leftEye, rightEye, localX, localY, localZ
-    const int cam_type = (int)blob[ext];
-    if (cam_type != 0) {
+    const int cam_type = PLANAR ? 0 : (int)blob[ext];
+    if (!PLANAR && cam_type != 0) {
         // camera_target_point, camera.c:506-555: spherical (VR) / cylindrical (panorama) screen
         const double azi = x * blob[ext + 1];
         double view_x, view_y, view_z;
@@ -214,7 +216,7 @@ NDT_DEV bool primary_node(const double *blob, const SceneDesc &sd, const Workspa
     v_copy<N>(cam, pos);
     if (eye == 0) blob_vec<N>(blob, ext + 3, cam);
     else if (eye == 2) blob_vec<N>(blob, ext + 3 + N, cam);
-    if (cam_type != 0 && eye != 1) {
+    if (!PLANAR && cam_type != 0 && eye != 1) {
         // VR: the eye goes round the centre with the view direction (ndt.c:519-525):
         // vectNd_rotate2(virtCam, pos, localX, localZ, azi) = vectNd.c:271-325 with vectNd_orthogonalize (vectNd.c:35-57)
         const double azi = x * blob[ext + 1];
@@ -524,7 +526,7 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         // before anything was traced); the node's record still goes to the pool for the kernels behind this one.
         double o[N], v[N];
         const bool make = PRIM && !in_seg;                      // (wave-uniform)
-        if (PRIM && make && live) live = primary_node<false>(gblob, sd, ws, job.rg, g, o, v);
+        if (PRIM && make && live) live = primary_node<false, true>(gblob, sd, ws, job.rg, g, o, v);
         // A lane without a ray.  The LDS tiers leave it out of the batch; in the global-memory tier it stays with the
         // wavefront as a helper of the coherent leaf scan (ndt_device.hpp:cls_scan: all 64 lanes fetch), with a ray that is
         // finished before it starts.
