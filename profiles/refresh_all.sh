@@ -16,7 +16,7 @@ trap give_back EXIT
 PART=${PART:-1}
 if [ "$PART" = 1 ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
-grep "bytes differ\|noisy values\|per-value t\|reference-equivalent rays" $O/tests.log > profiles/r04_gpu_test_notes.txt; tail -2 $O/tests.log >> profiles/r04_gpu_test_notes.txt; tail -2 $O/tests.log
+grep "bytes differ\|noisy values\|per-value t\|reference-equivalent rays\|sampler:\|inside their runs" $O/tests.log > profiles/r04_gpu_test_notes.txt; tail -2 $O/tests.log >> profiles/r04_gpu_test_notes.txt; tail -2 $O/tests.log
 for w in random4d balls4d hypercube3d; do
   bash profiles/profile_workload.sh $w || exit 1
 done
