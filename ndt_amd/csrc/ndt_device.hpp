@@ -707,24 +707,31 @@ NDT_DEV bool isect(const double *blob, const SceneDesc &sd, int prim, const doub
     }
 }
 
-// vect_bounding_sphere_intersect, bounding.c:34-85
+// vect_bounding_sphere_intersect, bounding.c:34-85, on a sphere record already read: centre, radius, radius^2
+template <int N>
+NDT_DEV bool bsphere_gate_rec(const double (&c)[N], const double rad, const double rad2, const double (&o)[N], const double (&v)[N],
+                              double min_dist)
+{
+    double oc[N];
+    v_sub<N>(o, c, oc);
+    double oc_len2 = v_dot<N>(oc, oc);
+    // (one verdict from all the comparisons, & and | instead of early returns: a return in the middle is a divergent branch,
+    // and what it skips -- one dot product -- costs less than the branch)
+    const double min_dist_r = min_dist + rad;
+    const bool too_far = (min_dist > 0) & (oc_len2 > min_dist_r * min_dist_r);
+    double voc = v_dot<N>(v, oc);
+    double voc2 = voc * voc;
+    double desc = voc2 - oc_len2 + rad2;
+    return !(too_far | (desc < 0.0) | ((voc > 0.0) & (voc2 > desc)));
+}
 template <int N>
 NDT_DEV bool bsphere_gate(const double *blob, const SceneDesc &sd, int obj, const double (&o)[N], const double (&v)[N],
                           double min_dist)
 {
     const int b = sd.off_bs + obj * (N + 2);
-    double c[N], oc[N];
+    double c[N];
     blob_vec<N>(blob, b, c);
-    v_sub<N>(o, c, oc);
-    double oc_len2 = v_dot<N>(oc, oc);
-    // (one verdict from all the comparisons, & and | instead of early returns: a return in the middle is a divergent branch,
-    // and what it skips -- one dot product -- costs less than the branch)
-    const double min_dist_r = min_dist + blob[b + N];
-    const bool too_far = (min_dist > 0) & (oc_len2 > min_dist_r * min_dist_r);
-    double voc = v_dot<N>(v, oc);
-    double voc2 = voc * voc;
-    double desc = voc2 - oc_len2 + blob[b + N + 1];
-    return !(too_far | (desc < 0.0) | ((voc > 0.0) & (voc2 > desc)));
+    return bsphere_gate_rec<N>(c, blob[b + N], blob[b + N + 1], o, v, min_dist);
 }
 
 // Ray (t >= 0) against the hull box of an hcube: N slabs { axis[N], centre, half extent }.
@@ -1674,11 +1681,19 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                 }
                 if (st == 1) {
                     NDT_COUNT(0);
-                    const ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
+                    ndt_v2d rec = blob_pair(blob, sd.off_kd + 2 * node);
                     // BITS: the items below this node that the ray has not visited yet.  None left: nothing in this subtree can
                     // change the ray's state any more (its leaves would scan nothing), so the walk does not enter it.
                     unsigned long long below = ~0ull;
-                    if (BITS) below = (unsigned long long)__double_as_longlong(blob[sd.off_nset + node]) & ~mask.w[0];
+                    if (BITS) {
+                        double ns = blob[sd.off_nset + node];
+#ifndef NDT_NO_T_HOIST
+                        // both reads in flight before the test of `below` (the compiler sinks the record's read behind it otherwise:
+                        // two LDS round trips in a row on the step's critical path)
+                        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(ns));
+#endif
+                        below = (unsigned long long)__double_as_longlong(ns) & ~mask.w[0];
+                    }
                     const long long w0 = __double_as_longlong(rec.x);
                     const int dim = (int)(w0 & 0xffffffffll);
                     if (BITS && below == 0ull) {
@@ -1827,7 +1842,28 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     gs = 4;                 // list exhausted
                 } else {
                     // one item of the list: visit mark, gate, and what passing the gate leads to
-                    auto scan_item = [&](const int id, const int flags, const bool masked) {
+                    // (LDS tiers: the item's sphere record is read together with its header word, ahead of the test of the gate flag
+                    // -- one LDS round trip on the step's critical path instead of two; every item has a record slot)
+                    #ifdef NDT_NO_SPHERE_AHEAD
+                    constexpr bool SPHERE_AHEAD = false;
+#else
+                    constexpr bool SPHERE_AHEAD = (MW != 0);
+#endif
+                    double sph_c[N], sph_r = 0.0, sph_r2 = 0.0;
+                    auto sphere_ahead = [&](const int id) {
+                        if constexpr (SPHERE_AHEAD) {
+                            const int b = sd.off_bs + id * (N + 2);
+                            blob_vec<N>(blob, b, sph_c);
+                            sph_r = blob[b + N];
+                            sph_r2 = blob[b + N + 1];
+                        }
+                    };
+                    auto scan_item = [&](const int id, int flags, const bool masked) {
+                        if constexpr (SPHERE_AHEAD) {
+                            asm volatile("" : "+v"(flags), "+v"(sph_r), "+v"(sph_r2));
+#pragma unroll
+                            for (int i = 0; i < N; ++i) asm volatile("" : "+v"(sph_c[i]));
+                        }
                         bool fresh = true;
                         if (masked) fresh = !mask.test_and_set(id);                             // object.c:707-713
                         // item boxes: a ray that misses the item's box cannot be given a hit by its intersect(); the gate
@@ -1844,7 +1880,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             const double gate_min = (gs == 1) ? sub_min : min_dist;
                             if (gs == 1) NDT_COUNT(1); else NDT_COUNT(3);
                             bool gate = true;
-                            if (flags & NDT_F_GATE) gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
+                            if (flags & NDT_F_GATE) {
+                                if constexpr (SPHERE_AHEAD) gate = bsphere_gate_rec<N>(sph_c, sph_r, sph_r2, o, v, gate_min);
+                                else gate = bsphere_gate<N>(blob, sd, id, o, v, gate_min);
+                            }
                             if (gate) {
                                 if ((flags & NDT_F_TYPE_MASK) == T_HCUBE) {
                                     // composites only occur in outer lists (validated at upload)
@@ -1880,6 +1919,7 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                         int id, flags;
                         blob_ref(blob, w_u, id, flags);
                         pos += 1;
+                        sphere_ahead(id);
                         scan_item(id, flags, !list_is_inf);
                     } else {
                         int id, flags;
@@ -1890,8 +1930,10 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                             cand ^= bit;
                             if (!list_is_inf) mask.w[0] |= bit;                         // object.c:713
                             flags = blob_int(blob, sd.off_hdr + 2 * id, 0);
+                            sphere_ahead(id);
                         } else {
                             blob_ref(blob, in_sub ? sd.off_child + sub_i : sec + pos, id, flags);
+                            sphere_ahead(id);
                         }
                         if (in_sub) {
                             // on to the next face whose box the ray meets (arithmetic shifts: all ones stays all ones)
