@@ -296,6 +296,15 @@ int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
  *   "stream_below"    auto: passes of up to this many primaries go to the streaming frame kernel
  *   "stream_below_list"  ... and passes over a list of samples (recursive anti-aliasing) of up to this many (default 30 000)
  *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
+ *   "face_tree"               0: hcubes of more than 63 faces without the hierarchy over their face boxes (ndt_hip_hcube_face_tree;
+ *                                tests prove it neutral)
+ *   "fuse_primaries"          per-bounce kernels: -1 auto (the first trace launch makes the primaries itself for a planar
+ *                                camera from 4-D on), 0 always a k_primary launch, 1 never one (planar camera)
+ *   "gate_prepass_below"      item-set scenes: passes of up to this many primaries mark the items whose bounding sphere the
+ *                                ray's line misses as visited before the walk (neutral; default 400 000)
+ *   "coop" (+ "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves")   item-set scenes, per-bounce kernels: a batch
+ *                                over its budget with few rays left gives them up to wavefronts that trace one ray each
+ *                                (ndt_device.hpp:coop_trace) -- bit-identical, measured slower, default 0
  *   "stream_fused"            0: the frame kernel between a k_primary and a k_finish_pixels launch instead of making its
  *                                primaries and writing its pixels itself (tests prove it neutral)
  *   "item_sets"               0: upload a scene of up to 64 items with plain leaf lists (the kernels that read the lists,
