@@ -26,6 +26,8 @@ if "--grid" in sys.argv:
     settings += [(1, b, k, 0, 4) for b in (60, 80) for k in (2, 4)]
 else:
     settings += [(1, 10, 16, 1, 4), (1, 10, 32, 1, 12), (1, 20, 64, 1, 12)]
+if "--off-only" in sys.argv:
+    settings = settings[:1]
 if "--probe" in sys.argv:
     g.set_option("exit_probe", 1)
     g.set_option("debug_levels", 1)
