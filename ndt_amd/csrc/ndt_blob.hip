@@ -961,6 +961,7 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
         if (want_pos && !vec_ok(fs, l.pos_off, 1)) return fail(NDT_E_INVALID, "light %d: position missing", i);
         if (want_dir && !vec_ok(fs, l.dir_off, 1)) return fail(NDT_E_INVALID, "light %d: direction missing", i);
         if (l.type != NDT_LIGHT_AMBIENT) ++n_shadow_lights;
+        else if (i < 64) sd.ambient_bits |= 1ull << i;
         b.push_ints(l.type, 0);
         b.push(l.red); b.push(l.green); b.push(l.blue);
         b.push(l.angle);

@@ -69,6 +69,7 @@ struct SceneDesc {
     // item boxes (global-memory tier): one orthonormal frame, N x axis[N], and per item N x { centre, half extent }
     int off_oframe, off_obox;      // off_obox == 0: none.  An item's slabs are stored thinnest first ...
     int off_oord;                  // ... one word per item: the frame axis of its j-th slab in bits 4j .. 4j+3
+    unsigned long long ambient_bits;    // bit l: light l is an ambient one (fires no shadow ray, has no segment of the shadow queue)
 };
 
 // ------------------------------------------------------------------ random streams

@@ -1027,14 +1027,23 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     double src[N], look[N], hit[N], nrm[N];
     int obj = -1;
     NDT_SEC_BEGIN();
-    if (in_range && ws.depth_left[g] > 0) {
-        obj = ws.hit_obj[g];
+    // The node's three words in flight TOGETHER (round 4): read one after the other -- is the node alive? -> what did it hit? ->
+    // which primitive? -- they were three round trips to HBM in a row at the head of a wavefront that lives for 6 us.
+    int dl = 0, obj_in = -1, prim_in = -1;
+    if (in_range) {
+        dl = ws.depth_left[g];
+        obj_in = ws.hit_obj[g];
+        prim_in = ws.hit_prim[g];
+        asm volatile("" : "+v"(dl), "+v"(obj_in), "+v"(prim_in));
+    }
+    if (in_range && dl > 0) {
+        obj = obj_in;
         if (obj >= 0) {
             load_soa<N>(ws.ray_o, ws.cap, g, src);
             load_soa<N>(ws.ray_v, ws.cap, g, look);
             // the hit point and normal trace_kd would have returned: re-run the one primitive
             // that won the traversal (same arithmetic, same result)
-            isect<N, true>(blob, sd, ws.hit_prim[g], src, look, hit, nrm);      // (always inline here: see NDT_SHADE_INLINE_ISECT)
+            isect<N, true>(blob, sd, prim_in, src, look, hit, nrm);      // (always inline here: see NDT_SHADE_INLINE_ISECT)
             const double trace_dist = v_dist<N>(hit, src);                  // ndt.c:365
             shaded = trace_dist > NDT_EPS;                                  // ndt.c:376
             if (rg.want_depth && level == 0) ws.depth[g] = shaded ? 1.0 / trace_dist : 0.0;    // ndt.c:366-370
@@ -1099,7 +1108,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
         const double refl_r = blob[mw + 3], refl_g = blob[mw + 4], refl_b = blob[mw + 5];
         const bool transparent = blob[mw + 7] != 0.0;
         const double frac = ws.frac[g];
-        depth_next = ws.depth_left[g] - 1;
+        depth_next = dl - 1;
         const double gb2 = (refl_g > refl_b) ? refl_g : refl_b;
         const double contrib = (refl_r > gb2) ? refl_r : gb2;
         int c_refl = -1, c_refr = -1;
@@ -1264,15 +1273,36 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
     const bool in_range = r < lr.count;
     const long long g = lr.begin + (in_range ? r : 0);
     int obj = -1;
-    if (in_range && ws.depth_left[g] > 0) obj = ws.hit_obj[g];
+    // (the node's words in flight together, as in shade_emit_node; and the answer of the FIRST shadow ray the lighting below will
+    // look at -- sh_mask -> sh_idx -> sobj / sprim, three more round trips in a row -- fetched while the hit point is recomputed)
+    int dl = 0, obj_in = -1, prim_in = -1;
+    unsigned long long fire = 0ull;
+    if (in_range) {
+        dl = ws.depth_left[g];
+        obj_in = ws.hit_obj[g];
+        prim_in = ws.hit_prim[g];
+        fire = ws.sh_mask[g];
+        asm volatile("" : "+v"(dl), "+v"(obj_in), "+v"(prim_in), "+v"(fire));
+    }
+    if (in_range && dl > 0) obj = obj_in;
     const bool shaded = obj >= 0;
 
     if (shaded) {
         double src[N], look[N], nrm[N], hit[N];
         load_soa<N>(ws.ray_o, ws.cap, g, src);
         load_soa<N>(ws.ray_v, ws.cap, g, look);
+        const unsigned long long ambient = sd.ambient_bits;
+        const unsigned long long fired = fire & ~ambient;
+        const int li_first = fired ? __ffsll((long long)fired) - 1 : -1;
+        int sobj_first = -1, sprim_first = -1;
+        if (li_first >= 0) {
+            const int seg = __popcll(~ambient & ((1ull << li_first) - 1ull));
+            const long long slot = (long long)seg * lr.seg_stride + ws.sh_idx[(long long)seg * ws.cap + g];
+            sobj_first = ws.sobj[slot];
+            sprim_first = ws.sprim[slot];
+        }
         // the hit point and normal trace_kd would have returned, as in shade_emit: same function, same operands, same bits
-        isect_full(blob, &sd, ws.hit_prim[g], src, look, hit, nrm);
+        isect_full(blob, &sd, prim_in, src, look, hit, nrm);
         const int mw = sd.off_mat + 8 * obj;
         const double hit_r = blob[mw], hit_g = blob[mw + 1], hit_b = blob[mw + 2];
         const double refl_r = blob[mw + 3], refl_g = blob[mw + 4], refl_b = blob[mw + 5];
@@ -1285,14 +1315,10 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
         double cr = hit_r * blob[sd.off_cam + 4 * N + 1];
         double cg = hit_g * blob[sd.off_cam + 4 * N + 2];
         double cb = hit_b * blob[sd.off_cam + 4 * N + 3];
-        const unsigned long long fire = ws.sh_mask[g];
         int n_shadow = 0;
         // Every lane walks ITS lights -- the ones that fired a shadow ray for this hit, and the ambient ones, in the list's
         // order (the sums below are taken in that order, ndt.c:98) -- not the whole list: on the benchmark scene a hit fires
         // 1.2 of its five point lights, and a loop over the list ran all five for every wavefront with a fifth of its lanes.
-        unsigned long long ambient = 0ull;
-        for (int li = 0; li < sd.n_lights; ++li)
-            if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) ambient |= 1ull << li;     // wave-uniform
         for (unsigned long long todo = fire | ambient; todo != 0ull; todo &= todo - 1ull) {
             const int li = __ffsll((long long)todo) - 1;
             const int w = light_word(sd, li);
@@ -1311,8 +1337,8 @@ NDT_DEV void shade_finish_node(const double *blob, const SceneDesc &sd, const Wo
             ShadowSetup ss;
             light_setup(blob, sd, li, src, hit, nrm, type, lgt_pos, rev_light, light_vec, so, ss,
                         rg.sample_keys ? ws.rng_key[g] : 0ull);
-            const int sobj = ws.sobj[slot];
-            const int sprim = ws.sprim[slot];
+            const int sobj = (li == li_first) ? sobj_first : ws.sobj[slot];
+            const int sprim = (li == li_first) ? sprim_first : ws.sprim[slot];
             ++n_shadow;
             bool lit;
             if (type == NDT_LIGHT_DIRECTIONAL_) {
