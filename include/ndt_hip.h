@@ -298,6 +298,7 @@ int ndt_hip_multi_path_taken(ndt_hip_ctx *ctx);
  *   "hull_box" / "face_box"   0: upload hcubes without the hull box / without the per-face boxes (tests prove them neutral)
  *   "face_tree"               0: hcubes of more than 63 faces without the hierarchy over their face boxes (ndt_hip_hcube_face_tree;
  *                                tests prove it neutral)
+ *   "face_groups"             0: ... without the index of their faces by thin hull axes (ndt_hip_hcube_face_groups; neutral)
  *   "fuse_primaries"          per-bounce kernels: -1 auto (the first trace launch makes the primaries itself for a planar
  *                                camera from 4-D on), 0 always a k_primary launch, 1 never one (planar camera)
  *   "gate_prepass_below"      item-set scenes: passes of up to this many primaries mark the items whose bounding sphere the
@@ -358,6 +359,17 @@ int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *scene, int32_t object
  * rows: n_nodes x dims x { centre, half extent }, level j starting at node level_off[j] (level_off: room for 32 ints).
  * Returns the number of nodes; with cap_nodes too small (or rows null) only that and *top.  0: no boxes, <0 on NDT_E_*. */
 int64_t ndt_hip_hcube_face_tree(const ndt_flat_scene *scene, int32_t object, int64_t cap_nodes, double *rows, int32_t *level_off, int32_t *top);
+
+/* Diagnostic, host only: the index the library lays over the faces of an hcube of more than 63 faces in 5-D and up (option
+ * "face_groups"): the faces by the set of hull axes their boxes are thin on.  clusters: dims x { centre-, half-, centre+, half+ }
+ * -- per hull axis the two intervals (one per side of the hull's centre; half -1: none) that hold the thin intervals of all
+ * faces thin on that axis; table: 2^dims x { start, count } -- for every subset S of the axes where in `members` (n_faces
+ * ints, may be null) the faces thin exactly on S stand, ascending; face_set: per face its S as a bit mask (-1: the face can
+ * never be hit).
+ * A ray can meet a face's box only if, inside the hull box, it passes a cluster interval on every axis of the face's S; the
+ * device looks up the subsets of the axes whose clusters the ray passes and tests their faces' own boxes.
+ * Returns the number of faces (0: the hcube gets no boxes), <0 on NDT_E_*. */
+int ndt_hip_hcube_face_groups(const ndt_flat_scene *scene, int32_t object, double *clusters, int32_t *table, int32_t *face_set, int32_t *members);
 
 /* Diagnostic, host only: the item boxes the library derives at upload for scenes of more than 256 items -- one orthonormal
  * frame for the scene (frame: dims x unit axis[dims]) and, for every top-level orthotope, the box in that frame of every

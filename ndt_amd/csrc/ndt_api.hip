@@ -61,7 +61,7 @@ extern "C" int ndt_hip_create(int device, ndt_hip_ctx **out)
     ctx->device = device;
     {
         // the environment is read here, once: nothing on the render or upload path looks at it
-        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "face_tree", "item_sets", "gate_prepass", "gate_prepass_below", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "fuse_primaries", "shade_pair", "debug_levels",
+        static const char *const names[] = { "hybrid_level", "stream_below", "stream_below_list", "hull_box", "face_box", "face_tree", "face_groups", "item_sets", "gate_prepass", "gate_prepass_below", "item_boxes", "leaf_history", "leaf_scan", "leaf_scan_group", "coop", "coop_budget_us", "coop_max_live", "coop_tail_only", "coop_waves", "multi_path", "sample_seed", "stream_fused", "fuse_primaries", "shade_pair", "debug_levels",
                                              "exit_probe", "shade_probe", "stream_probe", "test_small_pool" };
         const char *pl = getenv("NDT_HIP_PIPELINE");
         if (pl) (void)ndt_hip_set_option(ctx, "pipeline", !strcmp(pl, "levels") ? 1 : !strcmp(pl, "stream") ? 2 : !strcmp(pl, "hybrid") ? 3 : 0);
@@ -144,6 +144,7 @@ extern "C" int ndt_hip_set_option(ndt_hip_ctx *ctx, const char *name, int64_t va
     else if (!strcmp(name, "hull_box")) ctx->hull_box = on;
     else if (!strcmp(name, "face_box")) ctx->face_box = on;
     else if (!strcmp(name, "face_tree")) ctx->face_tree = on;
+    else if (!strcmp(name, "face_groups")) ctx->face_groups = on;
     else if (!strcmp(name, "item_sets")) ctx->item_sets = on;
     else if (!strcmp(name, "item_boxes")) ctx->item_boxes = on;
     else if (!strcmp(name, "gate_prepass_below")) ctx->gate_prepass_below = value;

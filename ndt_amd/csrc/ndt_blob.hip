@@ -59,6 +59,26 @@ extern "C" int64_t ndt_hip_hcube_face_tree(const ndt_flat_scene *fs, int32_t obj
     return n_nodes;
 }
 
+extern "C" int ndt_hip_hcube_face_groups(const ndt_flat_scene *fs, int32_t object, double *clusters_out, int32_t *table_out, int32_t *face_set_out,
+                                         int32_t *members_out)
+{
+    std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
+    const int rc = ndt_hip_hcube_hull_box(fs, object, hull.data());      // validates the arguments
+    if (rc <= 0) return rc;
+    if (!clusters_out || !table_out || !face_set_out) return fail(NDT_E_INVALID, "null argument");
+    std::vector<double> rows;
+    HullFaces hf;
+    if (!hcube_hull_box(fs, fs->objects[object], fs->dims, rows, &hf) || hf.n_faces == 0) return 0;
+    std::vector<double> clusters;
+    std::vector<int> table, face_set, members;
+    hcube_face_groups(hf, rows, fs->dims, clusters, table, face_set, members);
+    memcpy(clusters_out, clusters.data(), clusters.size() * sizeof(double));
+    memcpy(table_out, table.data(), table.size() * sizeof(int));
+    memcpy(face_set_out, face_set.data(), face_set.size() * sizeof(int));
+    if (members_out) memcpy(members_out, members.data(), members.size() * sizeof(int));
+    return hf.n_faces;
+}
+
 extern "C" int64_t ndt_hip_hcube_face_boxes_all(const ndt_flat_scene *fs, int32_t object, int64_t cap_faces, double *face_rows, uint8_t *possible)
 {
     std::vector<double> hull((size_t)(fs && fs->dims > 0 && fs->dims <= NDT_MAX_DIMS ? fs->dims * (fs->dims + 2) : 1));
@@ -364,6 +384,62 @@ void ndt_impl::hcube_face_tree(const HullFaces &hf, int n, std::vector<double> &
     }
 }
 
+// The faces of an hcube indexed by the hull axes their boxes are THIN on (ndt_device.hpp:hull_faces, NDT_F_FACEGROUPS).  An m-face
+// of an N-cube is pinned on N - m of the cube's axes and spans the other m: its box in the hull's frame is a sliver (two margins
+// wide) on the pinned axes.  A ray can meet the box only if, inside the hull, it passes through the sliver on EVERY pinned axis;
+// per axis all slivers lie in two clusters (the cube's two sides).  So the device finds the axes on which the ray passes a
+// cluster at all -- usually the one or two where it crosses the cube's surface -- and looks only at the faces whose pinned set is
+// a subset of those: table[S] = the list (ascending) of the faces pinned exactly on S.  Which axes count as thin is a heuristic
+// (a quarter of the hull's extent) and does not matter for correctness: a face listed under S has, on every axis of S, its
+// interval inside one of that axis's cluster intervals (they are made from exactly those faces), and every listed face is
+// still tested against its own box.
+void ndt_impl::hcube_face_groups(const HullFaces &hf, const std::vector<double> &hull_rows, int n, std::vector<double> &clusters,
+                                 std::vector<int> &table, std::vector<int> &face_set, std::vector<int> &members)
+{
+    const int nf = hf.n_faces;
+    std::vector<double> lo((size_t)n * 2, 1e300), hi((size_t)n * 2, -1e300);
+    face_set.assign((size_t)nf, 0);
+    table.assign((size_t)2 << n, 0);
+    for (int f = 0; f < nf; ++f) {
+        if (!((hf.possible[(size_t)f / NDT_HULL_CHUNK] >> (f % NDT_HULL_CHUNK)) & 1ull)) { face_set[(size_t)f] = -1; continue; }
+        int set = 0;
+        for (int a = 0; a < n; ++a) {
+            const double c = hf.rows[((size_t)f * n + a) * 2], h = hf.rows[((size_t)f * n + a) * 2 + 1];
+            const double hc = hull_rows[(size_t)a * (n + 2) + n], hh = hull_rows[(size_t)a * (n + 2) + n + 1];
+            if (h < 0.25 * hh) {
+                set |= 1 << a;
+                const int side = c < hc ? 0 : 1;
+                if (c - h < lo[(size_t)a * 2 + side]) lo[(size_t)a * 2 + side] = c - h;
+                if (c + h > hi[(size_t)a * 2 + side]) hi[(size_t)a * 2 + side] = c + h;
+            }
+        }
+        face_set[(size_t)f] = set;
+        table[(size_t)set * 2 + 1] += 1;
+    }
+    // table[S] = { start, count } of S's faces in `members`, ascending (the same axis set comes from several direction sets of a
+    // sheared cube -- its skewed faces are blobs, thin on every axis -- so the faces of a set need not be neighbours)
+    int at = 0;
+    for (size_t sset = 0; sset < ((size_t)1 << n); ++sset) {
+        table[sset * 2] = at;
+        at += table[sset * 2 + 1];
+        table[sset * 2 + 1] = 0;
+    }
+    members.assign((size_t)at, 0);
+    for (int f = 0; f < nf; ++f) {
+        const int set = face_set[(size_t)f];
+        if (set < 0) continue;
+        members[(size_t)table[(size_t)set * 2] + (size_t)table[(size_t)set * 2 + 1]++] = f;
+    }
+    clusters.assign((size_t)n * 4, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int side = 0; side < 2; ++side) {
+            const double l = lo[(size_t)a * 2 + side], h = hi[(size_t)a * 2 + side];
+            clusters[(size_t)a * 4 + side * 2] = (l <= h) ? 0.5 * (l + h) : 0.0;
+            // (centre +- half must hold [l, h] whatever the rounding of the two: a nanometre more; -1: no face is thin here)
+            clusters[(size_t)a * 4 + side * 2 + 1] = (l <= h) ? 0.5 * (h - l) + 1e-9 * (1.0 + fabs(l) + fabs(h)) : -1.0;
+        }
+}
+
 bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces)
 {
     std::vector<double> pts;
@@ -430,12 +506,77 @@ bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o
         }
         complete(frames[1], pc, 0.5);
     }
+    // A fourth candidate, taken whenever it exists (round 4): the DUAL basis of the cube's edge directions.  A slab test needs
+    // covectors, not an orthonormal frame -- w_k.(o + t v) in [lo, hi] bounds a convex region for any w_k -- and in the
+    // coordinates c_k = w_k.x with x = sum c_k d_k every face of a parallelotope is pinned EXACTLY on the coordinates of the
+    // directions it does not span, sheared cube or not: its box is two margins thin there (|w_k| = 1: a displacement moves a
+    // coordinate by at most its length, so the margins mean what they mean in an orthonormal frame).  In an orthonormal frame the
+    // faces of a sheared cube are slivers only on the first axes; the boxes of runs of them, and the clusters of
+    // hcube_face_groups, are wide.
+    bool have_dual = false;
+    {
+        std::vector<std::vector<double>> dirs;
+        for (const auto &a : axes) {
+            bool known = false;
+            for (const auto &d : dirs) {
+                double dot = 0;
+                for (int c = 0; c < n; ++c) dot += a[c] * d[c];
+                if (fabs(fabs(dot) - 1.0) < 1e-9) known = true;
+            }
+            if (!known) {
+                if ((int)dirs.size() == n) { dirs.clear(); break; }     // more directions than dimensions: not a parallelotope
+                dirs.push_back(a);
+            }
+        }
+        if ((int)dirs.size() == n) {
+            // x = sum c_k d_k  <=>  c = (D^T)^-1 x: Gauss-Jordan with partial pivoting on [D^T | I]
+            std::vector<double> m((size_t)n * 2 * n, 0.0);
+            for (int r = 0; r < n; ++r) {
+                for (int c = 0; c < n; ++c) m[(size_t)r * 2 * n + c] = dirs[(size_t)c][(size_t)r];
+                m[(size_t)r * 2 * n + n + r] = 1.0;
+            }
+            bool ok = true;
+            for (int col = 0; col < n && ok; ++col) {
+                int piv = col;
+                for (int r = col + 1; r < n; ++r)
+                    if (fabs(m[(size_t)r * 2 * n + col]) > fabs(m[(size_t)piv * 2 * n + col])) piv = r;
+                if (fabs(m[(size_t)piv * 2 * n + col]) < 1e-3) { ok = false; break; }       // nearly dependent directions
+                if (piv != col)
+                    for (int c = 0; c < 2 * n; ++c) std::swap(m[(size_t)piv * 2 * n + c], m[(size_t)col * 2 * n + c]);
+                const double d = m[(size_t)col * 2 * n + col];
+                for (int c = 0; c < 2 * n; ++c) m[(size_t)col * 2 * n + c] /= d;
+                for (int r = 0; r < n; ++r)
+                    if (r != col) {
+                        const double f = m[(size_t)r * 2 * n + col];
+                        if (f != 0.0)
+                            for (int c = 0; c < 2 * n; ++c) m[(size_t)r * 2 * n + c] -= f * m[(size_t)col * 2 * n + c];
+                    }
+            }
+            if (ok) {
+                std::vector<std::vector<double>> dual;
+                for (int k = 0; k < n && ok; ++k) {
+                    std::vector<double> w(m.begin() + (size_t)k * 2 * n + n, m.begin() + (size_t)k * 2 * n + 2 * n);
+                    const double l = h_len(w.data(), n);
+                    if (!(l > 0) || !std::isfinite(l) || l > 1e3) ok = false;     // (|w_k| = 1 / sin of d_k's angle to the others' span)
+                    else {
+                        for (int c = 0; c < n; ++c) w[(size_t)c] /= l;
+                        dual.push_back(w);
+                    }
+                }
+                if (ok) {
+                    frames.push_back(dual);
+                    have_dual = true;
+                }
+            }
+        }
+    }
     double best_cost = 0;
     int best = -1;
     std::vector<double> best_rows;
-    for (int fi = 0; fi < 3; ++fi) {
+    for (int fi = 0; fi < (int)frames.size(); ++fi) {
         auto &frame = frames[fi];
-        for (double keep = 0.5; (int)frame.size() < n && keep > 1e-4; keep *= 0.5) complete(frame, world, keep);
+        if (fi < 3)
+            for (double keep = 0.5; (int)frame.size() < n && keep > 1e-4; keep *= 0.5) complete(frame, world, keep);
         if ((int)frame.size() < n) continue;
         std::vector<double> cand, half((size_t)n);
         for (int a = 0; a < n; ++a) {
@@ -459,7 +600,7 @@ bool ndt_impl::hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o
                 if (c != a) prod *= half[c];
             cost += prod;
         }
-        if (best < 0 || cost < best_cost) {
+        if (best < 0 || cost < best_cost || (have_dual && fi == 3)) {
             best = fi;
             best_cost = cost;
             best_rows = cand;
@@ -840,6 +981,20 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
                     flags |= NDT_F_FACEBOX;
                     for (unsigned long long w : hf.possible) b.push_ints((int)(w & 0xffffffffull), (int)(w >> 32));
                     for (double x : hf.rows) b.push(x);
+                    if (hf.n_faces > NDT_HULL_CHUNK && ctx->face_groups && n >= 5) {
+                        // ... + the faces by the hull axes their boxes are thin on: n x { centre-, half-, centre+, half+ } of the
+                        // two clusters of slivers per axis, then one word { start, count } per subset of the axes, then the faces by subset
+                        flags |= NDT_F_FACEGROUPS;
+                        std::vector<double> clusters;
+                        std::vector<int> table, face_set, members;
+                        hcube_face_groups(hf, rows, n, clusters, table, face_set, members);
+                        for (double x : clusters) b.push(x);
+                        for (size_t k = 0; k < table.size(); k += 2) b.push_ints(table[k], table[k + 1]);
+                        // (one word per two members, as many words as two faces a word need whatever the number of members:
+                        // the device finds the hierarchy behind them without reading a length)
+                        members.resize((size_t)((hf.n_faces + 1) & ~1), 0);
+                        for (size_t k = 0; k < members.size(); k += 2) b.push_ints(members[k], members[k + 1]);
+                    }
                     if (hf.n_faces > NDT_HULL_CHUNK && ctx->face_tree) {
                         // ... + the hierarchy over them: { top level, 0 }, the levels' offsets (ints, two a word, in words
                         // from here), the rows of levels 1 .. top

@@ -85,6 +85,7 @@ struct ndt_hip_ctx {
     bool stream_probe = false, exit_probe = false, debug_levels = false, test_small_pool = false;
     bool hull_box = true, face_box = true, shade_pair = true;
     bool face_tree = true;          // hcubes of more than 63 faces: a hierarchy over the face boxes (ndt_device.hpp:hull_faces)
+    bool face_groups = true;        // ... and an index of the faces by the set of hull axes their boxes are thin on (hull_faces)
     // per-bounce kernels: the first trace launch makes the primaries it traces (no k_primary; k_trace's PRIM variant, planar camera).
     // -1: from 4-D on (measured, 1080p, on / off: benchmark frame 1.297 / 1.304 ms, balls 0.814 / 0.821, 6-D 1.298 / 1.326, 8-D 3.25 / 3.28;
     // 3-D 0.592 / 0.582 -- the variant spills a little more than the plain kernel, which the 2N doubles a ray it does not write and
@@ -164,6 +165,9 @@ struct HullFaces {
 };
 bool hcube_hull_box(const ndt_flat_scene *fs, const ndt_flat_object &o, int n, std::vector<double> &rows, HullFaces *faces = nullptr);
 void hcube_face_tree(const HullFaces &hf, int n, std::vector<double> &rows, std::vector<int> &level_off, int &top);
+// clusters: n x { centre-, half-, centre+, half+ }; table: 2^n x { start, count } (ints) into members; face_set: the thin axes of every face
+void hcube_face_groups(const HullFaces &hf, const std::vector<double> &hull_rows, int n, std::vector<double> &clusters, std::vector<int> &table,
+                       std::vector<int> &face_set, std::vector<int> &members);
 bool scene_item_boxes(const ndt_flat_scene *fs, int n, std::vector<double> &frame, std::vector<double> &rows, std::vector<char> &has);
 int build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs);
 

@@ -30,6 +30,7 @@
 #define NDT_F_FACEBOX     0x2000    /* ... followed by the mask of possible faces and every face's own box in that frame */
 #define NDT_F_OBOX        0x4000    /* the item carries a box in the scene's frame (ndt_blob.hip:scene_item_boxes) */
 #define NDT_F_FACETREE    0x8000    /* hcube of more than 63 faces: behind the face boxes, the boxes of every aligned run of 2^j faces (hull_faces) */
+#define NDT_F_FACEGROUPS  0x10000   /* ... and, between the face boxes and that hierarchy, the faces indexed by the hull axes their boxes are thin on (hull_faces) */
 
 enum { T_SPHERE = 0, T_HPLANE, T_HDISK, T_CYLINDER, T_HCYLINDER, T_ORTHOTOPE, T_HCUBE, T_HFACET, T_FACET };
 // light_type numbering of the reference, scene.h:23-31
@@ -767,6 +768,7 @@ NDT_DEV bool slab_interval_holds(double lo, double hi)
 // (more than 63 faces: the masks come 63 faces at a time -- `chunk` is where to start looking and, on return, the chunk of the
 // mask that came back: the first one from there on in which the ray meets a face's box)
 #define NDT_HULL_CHUNK 63
+#define NDT_GROUPS_MAX_AXES 6      /* hull_faces: a ray that passes the slivers of more axes than this takes the hierarchy */
 // Hcubes of more than 63 faces carry a hierarchy over their face boxes (NDT_F_FACETREE; round 4): level j holds, for every
 // aligned run [k 2^j, (k + 1) 2^j) of faces, the box of the union of their boxes.  The faces of an hcube come in groups of
 // 2^(N - m) consecutive ones that share their m directions and differ in the corner they hang on, low dimensions first
@@ -802,7 +804,7 @@ NDT_DEV bool hull_box_meets(const double *blob, int q, const double (&po)[N], co
 
 template <int N>
 NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf, const double (&o)[N], const double (&v)[N], int &chunk,
-                             const bool face_tree = false)
+                             const bool face_tree = false, const bool face_groups = false)
 {
     double po[N], inv[N];       // u_k.o and 1/(u_k.v); 0 marks a ray parallel to slab k
     double t0 = 0.0, t1 = NDT_DBL_MAX;
@@ -840,10 +842,68 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
     const int n_chunks = (nf + NDT_HULL_CHUNK - 1) / NDT_HULL_CHUNK;
     // (an hcube has more than 63 faces from 5-D on: the 3-D and 4-D kernels -- the benchmark scenes' -- do not carry the walk; in
     // their trace kernel its mere presence cost 2 %)
+    const int grp = fr + n_chunks + nf * 2 * N;                 // clusters and table of the face groups, when there are any
+    if (N >= 5 && face_groups) {
+        // The faces by the hull axes their boxes are thin on (ndt_blob.hip:hcube_face_groups).  On which axes does the ray, while
+        // it is inside the hull, pass one of the two clusters of slivers at all?  Usually one or two -- where it enters and
+        // leaves the cube.  Only faces pinned on a subset of those axes can be met: a handful of index ranges, each face of
+        // them against its own box.  (A ray along a diagonal passes many clusters: beyond NDT_GROUPS_MAX_AXES the walks below.)
+        unsigned int th = 0u;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            bool meets = false;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const double a = po[k] - blob[grp + 4 * k + 2 * side];
+                const double h = blob[grp + 4 * k + 2 * side + 1];
+                bool m;
+                if (inv[k] == 0.0) {
+                    m = !(fabs(a) > h);
+                } else {
+                    const double ta = (-h - a) * inv[k], tb = (h - a) * inv[k];
+                    double lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+                    if (t0 > lo) lo = t0;
+                    if (t1 < hi) hi = t1;
+                    m = slab_interval_holds(lo, hi);
+                }
+                meets |= m & (h >= 0.0);
+            }
+            th |= meets ? (1u << k) : 0u;
+        }
+        if (__popc(th) <= NDT_GROUPS_MAX_AXES) {
+            const int f_min = chunk * NDT_HULL_CHUNK;
+            int found = -1;
+            unsigned long long live = 0ull;
+            unsigned int sub = th;
+            const int mem = grp + 4 * N + (1 << N);             // the faces of every axis set, ascending, two to a word
+            while (true) {
+                const int start = blob_int(blob, grp + 4 * N + (int)sub, 0), count = blob_int(blob, grp + 4 * N + (int)sub, 1);
+                for (int i = start; i < start + count; ++i) {
+                    const int f = blob_int(blob, mem + (i >> 1), i & 1);
+                    if (f < f_min) continue;
+                    if (found >= 0 && f >= (found + 1) * NDT_HULL_CHUNK) break;        // (ascending: nothing of this set matters any more)
+                    if (hull_box_meets<N>(blob, fr + n_chunks + f * 2 * N, po, inv) &&
+                        (((unsigned long long)__double_as_longlong(blob[fr + f / NDT_HULL_CHUNK]) >> (f % NDT_HULL_CHUNK)) & 1ull) != 0ull) {
+                        const int ch = f / NDT_HULL_CHUNK;
+                        if (found < 0 || ch < found) {
+                            found = ch;
+                            live = 0ull;
+                        }
+                        live |= 1ull << (f - found * NDT_HULL_CHUNK);
+                    }
+                }
+                if (sub == 0u) break;
+                sub = (sub - 1u) & th;
+            }
+            if (found < 0) return 0;
+            chunk = found;
+            return (long long)live;
+        }
+    }
     if (N >= 5 && face_tree) {
         // the faces whose box the ray meets, from face 63 `chunk` on, in face order: the first one names the chunk that is
         // reported, the walk goes on to that chunk's end
-        const int tree = fr + n_chunks + nf * 2 * N;            // { levels, offset of level 1 .. } then the levels' rows
+        const int tree = grp + (face_groups ? 4 * N + (1 << N) + ((nf + 1) >> 1) : 0);    // { levels, offset of level 1 .. } then the levels' rows
         const int top = blob_int(blob, tree, 0);                // the highest level (2^top >= nf)
         int i = chunk * NDT_HULL_CHUNK;
         int found = -1;
@@ -1811,7 +1871,8 @@ NDT_DEV void trace_kd(const double *blob, const SceneDesc &sd, VisitMask<MW> &ma
                     int chunk = (sub_i - first) / NDT_HULL_CHUNK;
                     if (oflags & NDT_F_BOX)
                         live = hull_faces<N>(blob, sd.off_params + blob_int(blob, sd.off_hdr + 2 * sub_owner, 1),
-                                             (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk, (oflags & NDT_F_FACETREE) != 0);
+                                             (oflags & NDT_F_FACEBOX) != 0, sub_end - first, o, v, chunk, (oflags & NDT_F_FACETREE) != 0,
+                                             (oflags & NDT_F_FACEGROUPS) != 0);
                     if (live == 0) {
                         // (an hcube just entered: it never began -- no result to apply, the scan goes on in this very step)
                         if (fresh_hcube) gs = 0;
@@ -2121,7 +2182,7 @@ NDT_DEV void coop_trace(const double *blob, const SceneDesc &sd, const double (&
                     if (live == 0 && !all_faces) {
                         long long lv = -1;
                         int ch = chunk;
-                        if (flags & NDT_F_BOX) lv = hull_faces<N>(blob, pbox, (flags & NDT_F_FACEBOX) != 0, nf, o, v, ch, (flags & NDT_F_FACETREE) != 0);
+                        if (flags & NDT_F_BOX) lv = hull_faces<N>(blob, pbox, (flags & NDT_F_FACEBOX) != 0, nf, o, v, ch, (flags & NDT_F_FACETREE) != 0, (flags & NDT_F_FACEGROUPS) != 0);
                         if (lv == 0) {
                             cube_open = false;          // the ray misses the hull box, or every face box from `chunk` on
                         } else if (lv == -1) {

@@ -314,6 +314,9 @@ template <int MW> NDT_DEV void init_visit_mask(VisitMask<MW> &mask, const double
 // COOPK: the variant with the straggler ring (TraceJob::coop_ring; option `coop`); PRIM: the variant whose dense part is the
 // pass's primaries, made here (TraceJob::make_primaries).  Both are variants, not run-time branches: the code of either in the
 // kernel cost the launches that do not use it 2-3 % (registers and scratch around the traversal loop).
+#ifndef NDT_TICKET_AHEAD
+#define NDT_TICKET_AHEAD 256
+#endif
 template <int MW, bool LDS, bool LSTACK = false, bool COOPK = false, bool PRIM = false>
 __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_MAX_BLOCK) k_trace(const double *__restrict__ gblob, SceneDesc sd, Workspace ws, TraceJob job)
 {
@@ -454,9 +457,24 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
     int cur = blockIdx.x % NDT_QUEUE_SHARDS;                    // home shard
     long long last_k = -1;                                      // this wavefront's last pop from `cur`
     bool any_left = true;
+    // A ticket drawn ahead (round 4; global-memory tier only -- measured: 6-D 1.263 -> 1.231 ms, 7-D / 8-D equal, but the LDS tiers
+    // slower: benchmark frame 1.253 -> 1.275, balls 0.792 -> 0.854): while the shard is far from its end (NDT_TICKET_AHEAD tickets: every wavefront that draws
+    // from it could take several before it runs dry), the next pop's atomic is issued ahead of this batch's ray loads and travels
+    // with them -- a pop was a round trip of its own, ~2 us of a 10-40 us batch.  Near the end nothing is held back: a ticket in the
+    // pocket of a wavefront in a long batch would be a batch nobody else can start.
+    int k_ahead = -1;
     while (true) {
         long long b = -1;           // logical batch
-        while (any_left) {
+        if (k_ahead >= 0) {
+            const int k = __shfl(k_ahead, 0, 64);
+            const long long n_here = (n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;
+            k_ahead = -1;
+            if (k < n_here) {
+                b = (long long)k * NDT_QUEUE_SHARDS + cur;
+                last_k = k;
+            }
+        }
+        while (any_left && b < 0) {
             const long long n_here = (n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS;     // batches of this shard
             bool may = true;
             if (reserve > 0 && last_k + 1 + 4 * reserve >= n_here) {
@@ -490,6 +508,13 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
             }
         }
         if (b < 0) break;
+#ifndef NDT_NO_TICKET_AHEAD
+        if (MW == 0 && last_k + NDT_TICKET_AHEAD < (n_batches - cur + NDT_QUEUE_SHARDS - 1) / NDT_QUEUE_SHARDS) {
+            // (every lane is here; the atomic travels with this batch's ray loads and is back when they are)
+            k_ahead = 0;
+            if (lane == 0) k_ahead = atomicAdd(job.queue + cur * NDT_QUEUE_STRIDE, 1);
+        }
+#endif
         if (job.exit_log) probe_batch = (unsigned int)wall_clock64();
         TraceAbandon ab{};
         if (COOP && coop_on) {

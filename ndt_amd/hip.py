@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 API_SYMBOLS = [
     "ndt_hip_create", "ndt_hip_destroy", "ndt_hip_upload_scene", "ndt_hip_render_device", "ndt_hip_render",
     "ndt_hip_trace_rays", "ndt_hip_quantize_device", "ndt_hip_shard_rows", "ndt_hip_stream",
-    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes", "ndt_hip_hcube_face_boxes_all", "ndt_hip_hcube_face_tree",
+    "ndt_hip_synchronize", "ndt_hip_last_error", "ndt_hip_abi_version", "ndt_hip_hcube_hull_box", "ndt_hip_hcube_face_boxes", "ndt_hip_hcube_face_boxes_all", "ndt_hip_hcube_face_tree", "ndt_hip_hcube_face_groups",
     "ndt_hip_render_depth_device", "ndt_hip_render_depth", "ndt_hip_render_rgba8", "ndt_hip_render_multi_device",
     "ndt_hip_render_multi", "ndt_hip_device_count", "ndt_hip_device", "ndt_hip_set_option", "ndt_hip_multi_path_taken",
     "ndt_hip_item_boxes", "ndt_hip_render_rgba8_async", "ndt_hip_render_rgba8_wait",
@@ -73,6 +73,9 @@ def load_library():
     lib.ndt_hip_hcube_face_boxes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ndt_hip_hcube_face_boxes_all.restype = C.c_int64
+    if hasattr(lib, "ndt_hip_hcube_face_groups"):
+        lib.ndt_hip_hcube_face_groups.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ndt_hip_hcube_face_groups.restype = C.c_int
     if hasattr(lib, "ndt_hip_hcube_face_tree"):     # (absent from round 3's library, which profiles/ab_libs.sh still loads to compare builds)
         lib.ndt_hip_hcube_face_tree.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ndt_hip_hcube_face_tree.restype = C.c_int64
@@ -158,6 +161,26 @@ def hcube_face_tree(fs, obj):
         end = off[j + 1] if j < top.value else count
         levels.append((rows[off[j]:end, :, 0].copy(), rows[off[j]:end, :, 1].copy()))
     return levels
+
+
+def hcube_face_groups(fs, obj):
+    """The index of hcube `obj`'s faces by the hull axes their boxes are thin on (host only, no GPU):
+    (clusters[N, 2, 2] = per axis and side {centre, half}, table[2^N, 2] = {start, count} per subset of the axes into members,
+    face_set[n_faces], members); None when the hcube gets no face boxes."""
+    import numpy as np
+    lib = load_library()
+    n = fs.dims
+    nf = fs.objects[int(obj)]["n_obj"]
+    clusters = np.zeros((n, 2, 2), dtype=np.float64)
+    table = np.zeros((1 << n, 2), dtype=np.int32)
+    face_set = np.zeros(max(nf, 1), dtype=np.int32)
+    members = np.zeros(max(nf, 1), dtype=np.int32)
+    rc = lib.ndt_hip_hcube_face_groups(fs.byref(), int(obj), clusters.ctypes.data, table.ctypes.data, face_set.ctypes.data, members.ctypes.data)
+    if rc < 0:
+        raise NdtHipError(int(rc), (lib.ndt_hip_last_error() or b"").decode())
+    if rc == 0:
+        return None
+    return clusters, table, face_set[:rc], members[:int((face_set[:rc] >= 0).sum())]
 
 
 class NdtHip:

@@ -47,7 +47,7 @@ def aimed_rays(fs, box_of, seed, per_target=6):
         if box is not None:
             ax, c, half = box
             for _ in range(8 * per_target):
-                targets.append((c + rng.uniform(-1, 1, n) * half) @ ax)
+                targets.append(np.linalg.solve(ax, c + rng.uniform(-1, 1, n) * half))     # frame coordinates -> world
     targets = np.array(targets)
     d = rng.normal(0, 1, targets.shape)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
@@ -73,7 +73,8 @@ def test_every_oracle_hit_on_an_hcube_lies_inside_its_hull_box(oracle, name):
     for b in boxes.values():
         if b is not None:
             ax = b[0]
-            assert np.abs(ax @ ax.T - np.eye(fs.dims)).max() < 1e-12      # orthonormal frame
+            # unit covectors: an orthonormal frame, or the dual basis of the cube's edge directions (a slab test needs no more)
+            assert np.abs(np.linalg.norm(ax, axis=1) - 1).max() < 1e-12 and abs(np.linalg.det(ax)) > 1e-6
     rays = aimed_rays(fs, boxes.get, seed=11)
     obj, hit, _ = oracle.trace(fs, rays)
     n_hits = 0
@@ -177,6 +178,45 @@ def test_face_tree_runs_hold_their_faces(oracle, name):
     print("%s: %d reference hits on hcubes of more than 63 faces, all inside their runs" % (name, n_in))
 
 
+@pytest.mark.parametrize("name", SCENES + ["zoo9d"])
+def test_face_groups_list_every_face_under_axes_whose_clusters_hold_it(name):
+    """The index of an hcube's faces by the hull axes their boxes are thin on (ndt_hip_hcube_face_groups): every face that can
+    be hit is in the (ascending) list of its axis set, and on every axis of that set its interval lies inside one of the axis's
+    two cluster intervals -- so a ray that meets the face's box inside the hull passes a cluster on each of those axes, which is
+    all the device's lookup relies on (it tests every listed face against its own box)."""
+    from ndt_amd.hip import hcube_face_boxes, hcube_face_groups
+    fs = golden(name).scene
+    big = [h for h in hcubes(fs) if fs.objects[h]["n_obj"] > 63]
+    if not big:
+        pytest.skip("no hcube of more than 63 faces in this scene")
+    for h in big:
+        faces, groups = hcube_face_boxes(fs, h), hcube_face_groups(fs, h)
+        if faces is None:
+            assert groups is None
+            continue
+        centre, half, live = faces
+        clusters, table, face_set, members = groups
+        n = fs.dims
+        assert len(face_set) == len(centre)
+        assert ((face_set < 0) == ~live).all()
+        lo, hi = centre - half, centre + half
+        c_lo, c_hi = clusters[:, :, 0] - clusters[:, :, 1], clusters[:, :, 0] + clusters[:, :, 1]       # [axis, side]
+        c_hi = np.where(clusters[:, :, 1] < 0, -np.inf, c_hi)
+        pinned = 0
+        for f in np.flatnonzero(live):
+            s = int(face_set[f])
+            mine = members[table[s, 0]:table[s, 0] + table[s, 1]]
+            assert f in mine and (np.diff(mine) > 0).all()
+            for a in range(n):
+                if s >> a & 1:
+                    assert ((c_lo[a] <= lo[f, a]) & (hi[f, a] <= c_hi[a])).any()
+                    pinned += 1
+        # an m-face of a cube is pinned on N - m >= 1 axes: the index has something to select by
+        assert pinned >= int(live.sum())
+        print("%s: hcube %d: %d faces under %d axis sets, %.2f pinned axes a face" % (name, h, int(live.sum()), len(set(face_set[live].tolist())),
+                                                                                         pinned / max(1, int(live.sum()))))
+
+
 def test_hull_box_of_a_non_hcube_is_an_error():
     from ndt_amd.hip import hcube_hull_box, NdtHipError
     fs = golden("c3_random4d").scene
@@ -209,14 +249,22 @@ def test_cull_changes_nothing_on_the_device(oracle, name):
         gpu.set_option("face_tree", 0)                  # face boxes walked linearly, 63 at a time (hcubes of more than 63 faces)
         gpu.upload_scene(fs)
         no_tree = gpu.trace_rays(rays)
-        gpu.set_option("face_tree", 1)
+        gpu.set_option("face_groups", 0)                # ... neither the hierarchy nor the index by thin axes
+        gpu.upload_scene(fs)
+        linear = gpu.trace_rays(rays)
+        gpu.set_option("face_tree", 1)                  # the hierarchy alone (round 4's first version)
+        gpu.upload_scene(fs)
+        tree_only = gpu.trace_rays(rays)
+        gpu.set_option("face_groups", 1)
     finally:
         gpu.close()
-    for a, b, c, d, e in zip(got, plain, want, hull_only, no_tree):
+    for a, b, c, d, e, f, g in zip(got, plain, want, hull_only, no_tree, linear, tree_only):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)
         assert np.array_equal(a, d)
         assert np.array_equal(a, e)
+        assert np.array_equal(a, f)
+        assert np.array_equal(a, g)
 
 
 def axis_rays(fs, seed):
@@ -237,11 +285,12 @@ def axis_rays(fs, seed):
         if faces is not None:
             centre, fhalf, live = faces
             spots += [centre[f] + rng.uniform(-1, 1, n) * fhalf[f] for f in np.flatnonzero(live)[:24]]
+        back = np.linalg.inv(ax)
         for s in spots:
-            p = s @ ax                                                      # frame coordinates -> world
+            p = np.linalg.solve(ax, s)                                      # frame coordinates -> world
             for k in range(n):
                 for sign in (1.0, -1.0):
-                    d = sign * ax[k]
+                    d = sign * back[:, k] / np.linalg.norm(back[:, k])      # moves coordinate k only (ax[k] itself in an orthonormal frame)
                     rays.append(np.concatenate([p - d * rng.uniform(3, 9), d, [-1.0]]))
                     rays.append(np.concatenate([p, d, [-1.0]]))             # starts where it aims
                     g = d + 1e-3 * rng.normal(0, 1, n)                      # shallow against the other slabs
@@ -251,7 +300,7 @@ def axis_rays(fs, seed):
         for k in range(n):
             e = np.zeros(n)
             e[k] = 1.0
-            p = (c + rng.uniform(-1, 1, n) * half) @ ax
+            p = np.linalg.solve(ax, c + rng.uniform(-1, 1, n) * half)
             rays.append(np.concatenate([p - 5 * e, e, [-1.0]]))
     return np.array(rays)
 
