@@ -981,7 +981,7 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
                     flags |= NDT_F_FACEBOX;
                     for (unsigned long long w : hf.possible) b.push_ints((int)(w & 0xffffffffull), (int)(w >> 32));
                     for (double x : hf.rows) b.push(x);
-                    if (hf.n_faces > NDT_HULL_CHUNK && ctx->face_groups && n >= 5) {
+                    if (hf.n_faces > NDT_HULL_CHUNK && ctx->face_groups && n >= NDT_GROUPS_MIN_DIMS) {
                         // ... + the faces by the hull axes their boxes are thin on: n x { centre-, half-, centre+, half+ } of the
                         // two clusters of slivers per axis, then one word { start, count } per subset of the axes, then the faces by subset
                         flags |= NDT_F_FACEGROUPS;

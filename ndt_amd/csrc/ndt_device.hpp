@@ -768,6 +768,12 @@ NDT_DEV bool slab_interval_holds(double lo, double hi)
 // (more than 63 faces: the masks come 63 faces at a time -- `chunk` is where to start looking and, on return, the chunk of the
 // mask that came back: the first one from there on in which the ray meets a face's box)
 #define NDT_HULL_CHUNK 63
+// (from 9-D on: in the 6-D .. 8-D trace kernels of the global-memory tier the lookup's mere presence cost 25 spilled registers and
+// 1-3 % of the hypercube frames, which have no hcube at all; a 6-D hcube's 472 faces gain 4 % from it, a 9-D one's 16 866 a third.
+// As a real function it was no better: the registers live across the call are saved around it -- 110 spilled either way.)
+#ifndef NDT_GROUPS_MIN_DIMS
+#define NDT_GROUPS_MIN_DIMS 9
+#endif
 #define NDT_GROUPS_MAX_AXES 6      /* hull_faces: a ray that passes the slivers of more axes than this takes the hierarchy */
 // Hcubes of more than 63 faces carry a hierarchy over their face boxes (NDT_F_FACETREE; round 4): level j holds, for every
 // aligned run [k 2^j, (k + 1) 2^j) of faces, the box of the union of their boxes.  The faces of an hcube come in groups of
@@ -843,7 +849,7 @@ NDT_DEV long long hull_faces(const double *blob, int p, bool face_boxes, int nf,
     // (an hcube has more than 63 faces from 5-D on: the 3-D and 4-D kernels -- the benchmark scenes' -- do not carry the walk; in
     // their trace kernel its mere presence cost 2 %)
     const int grp = fr + n_chunks + nf * 2 * N;                 // clusters and table of the face groups, when there are any
-    if (N >= 5 && face_groups) {
+    if (N >= NDT_GROUPS_MIN_DIMS && face_groups) {
         // The faces by the hull axes their boxes are thin on (ndt_blob.hip:hcube_face_groups).  On which axes does the ray, while
         // it is inside the hull, pass one of the two clusters of slivers at all?  Usually one or two -- where it enters and
         // leaves the cube.  Only faces pinned on a subset of those axes can be met: a handful of index ranges, each face of
