@@ -23,6 +23,15 @@ done
 give_back
 exit 0
 fi
+if [ "$PART" = 3 ]; then
+# the zoo by dimension and by face cull, the exit probe and kernel timeline of the benchmark frame, the soak
+timeout -k 10 300 python profiles/zoo_cull_probe.py 2>&1 | grep -v amdgpu > profiles/r04_zoo_by_face_cull.txt; cat profiles/r04_zoo_by_face_cull.txt
+timeout -k 10 200 python profiles/zoo_probe.py 2>&1 | grep -v amdgpu > $O/r04_zoo_probe.txt
+timeout -k 10 120 python3 profiles/coop_probe.py c3_random4d 1920x1080 1 --probe --off-only 2>&1 | grep -v "amdgpu\|SIMD 0/1" | cut -c1-400 > profiles/r04_exit_probe_c3.txt
+timeout -k 10 400 python profiles/soak.py 150 > $O/soak.log 2>&1; tail -12 $O/soak.log > profiles/r04_soak.txt; tail -3 profiles/r04_soak.txt
+give_back
+exit 0
+fi
 for w in hypercube6d hypercube7d hypercube8d; do
   bash profiles/profile_workload.sh $w || exit 1
 done
