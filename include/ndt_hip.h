@@ -339,7 +339,10 @@ int32_t ndt_hip_shard_rows(int32_t height, int32_t row_begin, int32_t row_step);
  * of `scene` at upload time -- an oriented box that contains every point orthotope.intersect
  * (orthotope.c:150-300) can return for the hcube's faces; rays that miss it skip the nested
  * trace() over the faces (hcube.c:241), which cannot change the answer.  rows receives
- * dims x { unit axis[dims], centre coordinate, half extent }.  Returns 1 when the hcube has a
+ * dims x { unit axis[dims], centre coordinate, half extent }: the region |axis_k . x - centre_k| <= half_k for every k.  The
+ * axes are unit covectors -- an orthonormal frame, or, when the hcube is a parallelotope, the normalised dual basis of its
+ * edge directions (axis_k . d_j = 0 for j != k), in which every face is thin exactly on the directions it does not span;
+ * they need not be orthogonal to each other.  Returns 1 when the hcube has a
  * box, 0 when it has none (its faces are always scanned), <0 on NDT_E_*. */
 int ndt_hip_hcube_hull_box(const ndt_flat_scene *scene, int32_t object, double *rows);
 
