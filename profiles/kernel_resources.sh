@@ -32,10 +32,11 @@ for name, r in rows.items():
     if not r or "k_" not in name:
         continue
     try:
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
+        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        dem = dem.split("(")[0].replace("void ", "")
     except Exception:
         dem = name
-    print("  %-62s %4d / %4d / %5d / %d" % (dem[-62:], r.get("VGPRs", 0), r.get("VGPRs Spill", 0), r.get("ScratchSize \\[bytes/lane\\]", 0), r.get("Occupancy \\[waves/SIMD\\]", 0)))
+    print("  %-58s %4d / %4d / %5d / %d" % (dem[-58:], r.get("VGPRs", 0), r.get("VGPRs Spill", 0), r.get("ScratchSize \\[bytes/lane\\]", 0), r.get("Occupancy \\[waves/SIMD\\]", 0)))
 PY
 done
 rm -rf $tmp
