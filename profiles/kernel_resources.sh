@@ -32,7 +32,7 @@ for name, r in rows.items():
     if not r or "k_" not in name:
         continue
     try:
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
         dem = dem.split("(")[0].replace("void ", "")
     except Exception:
         dem = name
