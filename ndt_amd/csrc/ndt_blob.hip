@@ -1157,6 +1157,9 @@ int ndt_impl::build_blob(ndt_hip_ctx *ctx, const ndt_flat_scene *fs)
     // tier 0: trace sections fit the LDS budget and the visit mask fits registers
     const bool fits_lds = (size_t)sd.trace_words * sizeof(double) <= NDT_TRACE_LDS_LIMIT;
     ctx->tier = (fits_lds && sd.mask_words <= NDT_MASK_REG_WORDS) ? 0 : 1;
+    // (LDS tiers only: in the global-memory tier's trace kernel the few lines that find a segment's light cost more -- spilled
+    // registers at 6-D .. 8-D -- than the origins' traffic: hypercube frames +1 .. +2.5 %, measured)
+    sd.light_origins = ctx->tier == 0 ? 1 : 0;
     // Leaf history (ndt_device.hpp:VisitMask<0>): the items of every leaf as a bit set + every leaf's list range, when
     // every leaf list ascends in item number (a scan that stopped after item `last` then visited the leaf's items <= last)
     sd.off_lset = sd.off_lrange = 0;

@@ -71,6 +71,7 @@ struct SceneDesc {
     int off_oframe, off_obox;      // off_obox == 0: none.  An item's slabs are stored thinnest first ...
     int off_oord;                  // ... one word per item: the frame axis of its j-th slab in bits 4j .. 4j+3
     unsigned long long ambient_bits;    // bit l: light l is an ambient one (fires no shadow ray, has no segment of the shadow queue)
+    int light_origins;                  // 1: the shadow rays of point / spot lights are stored without their origin (k_trace takes the light's position)
 };
 
 // ------------------------------------------------------------------ random streams

@@ -717,6 +717,7 @@ int ndt_impl::render_pass(ndt_hip_ctx *ctx, RenderGeom rg, bool prof, void *d_rg
                 TraceJob tj{};
                 tj.n_seg = n_seg;
                 tj.seg.o = ws.so; tj.seg.v = ws.sv; tj.seg.stride = ws.sh_cap; tj.seg.lim = ws.slim; tj.seg.valid = nullptr;
+                tj.seg_light_origins = sd_pass.light_origins;      // (what shade_emit_node left out: ndt_kernels.hip)
                 tj.seg.out_obj = ws.sobj; tj.seg.out_prim = ws.sprim;
                 tj.seg_count = NDT_SEG_COUNTERS(ws, b);
                 tj.seg_stride = (upper + 63) & ~63LL;           // sizes the grid only

@@ -314,6 +314,19 @@ template <int MW> NDT_DEV void init_visit_mask(VisitMask<MW> &mask, const double
 // COOPK: the variant with the straggler ring (TraceJob::coop_ring; option `coop`); PRIM: the variant whose dense part is the
 // pass's primaries, made here (TraceJob::make_primaries).  Both are variants, not run-time branches: the code of either in the
 // kernel cost the launches that do not use it 2-3 % (registers and scratch around the traversal loop).
+// Where the rays of shadow segment s start, when they all start at one point: the position of the s-th light that is not
+// ambient, if it is a point or a spot light (ndt.c:211; light record: ndt_blob.hip) -- else -1 (directional: the nudged hit
+// points; area lights: a point of the light per ray).  s: the same in every lane.
+NDT_DEV int seg_light_origin(const double *gblob, const SceneDesc &sd, int s)
+{
+    unsigned long long rest = ~sd.ambient_bits;
+    for (int k = 0; k < s; ++k) rest &= rest - 1ull;
+    const int li = __ffsll((long long)rest) - 1;
+    const int w = sd.off_lights + li * (6 + 4 * N);
+    const int type = blob_int(gblob, w, 0);
+    return (type == NDT_LIGHT_POINT_ || type == NDT_LIGHT_SPOT_) ? w + 5 : -1;
+}
+
 #ifndef NDT_TICKET_AHEAD
 #define NDT_TICKET_AHEAD 256
 #endif
@@ -531,10 +544,12 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
         long long g;
         bool live;
         const bool in_seg = b >= dense_batches;         // wave-uniform
+        int origin_word = -1;                           // >= 0: every ray of this batch starts at the light whose position stands there
         if (in_seg) {
             // segment of shadow batch sb = number of segments whose inclusive prefix is <= sb
             const int sb = (int)(b - dense_batches);
             const int s = __popcll(__ballot(lane < job.n_seg && seg_batches_incl <= sb));
+            if (MW != 0 && job.seg_light_origins) origin_word = seg_light_origin(gblob, sd, __builtin_amdgcn_readfirstlane(s));
             const int first = (s > 0) ? __shfl(seg_batches_incl, s - 1, 64) : 0;
             const int cnt = __shfl(seg_cnt, s, 64);
             const int idx = (sb - first) * bs + lane;
@@ -565,7 +580,8 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
 #endif
         if (live) {
             if (!make) {
-                load_soa<N>(part.o, part.stride, g, o);
+                if (origin_word >= 0) blob_vec<N>(gblob, origin_word, o);
+                else load_soa<N>(part.o, part.stride, g, o);
                 load_soa<N>(part.v, part.stride, g, v);
             }
         } else {
@@ -704,7 +720,9 @@ __global__ void __launch_bounds__(MW == 0 ? NDT_TRACE_T1_MAX_BLOCK : NDT_TRACE_M
                 const TracePart &part = in_seg ? job.seg : job.dense;
                 double o[N], v[N];
                 // (a launch with the ring never makes its own primaries: what it is given up was stored by an earlier kernel)
-                load_soa<N>(part.o, part.stride, g, o);
+                const int origin_word = (in_seg && job.seg_light_origins) ? seg_light_origin(gblob, sd, (int)(g / seg_stride)) : -1;
+                if (origin_word >= 0) blob_vec<N>(gblob, origin_word, o);
+                else load_soa<N>(part.o, part.stride, g, o);
                 load_soa<N>(part.v, part.stride, g, v);
                 const double lim = part.lim ? part.lim[g] : -1.0;
                 // the next ticket travels while this ray is traced (issued behind the ray's loads: memory operations return in order)
@@ -1219,7 +1237,11 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
     // 1080p frames 2-4 % slower; these launches are throughput-bound and the shuffles cost more than the idle iterations)
     seg = 0;
     for (int li = 0; live && li < sd.n_lights; ++li) {
-        if (blob_int(blob, light_word(sd, li), 0) == NDT_LIGHT_AMBIENT_) continue;
+        const int list_type = blob_int(blob, light_word(sd, li), 0);        // (wave-uniform)
+        if (list_type == NDT_LIGHT_AMBIENT_) continue;
+        // a point or spot light's shadow rays start at the light: the trace launch takes the origin from the light's record
+        // (TraceJob::seg_light_origins, k_trace) -- 8 N bytes a ray less to write here and to read there
+        const bool origin_known = sd.light_origins && (list_type == NDT_LIGHT_POINT_ || list_type == NDT_LIGHT_SPOT_);
         const bool fires = (fire >> li) & 1ull;
         const unsigned long long vote = __ballot(fires);
         const int base = __shfl(my_base, seg, 64);
@@ -1231,7 +1253,7 @@ NDT_DEV void shade_emit_node(const double *blob, const SceneDesc &sd, const Work
             const int idx = base + __popcll(vote & ((1ull << lane) - 1ull));
             const long long slot = (long long)seg * lr.seg_stride + idx;
             ws.sh_idx[(long long)seg * ws.cap + g] = idx;
-            store_soa<N>(ws.so, ws.sh_cap, slot, so);
+            if (!origin_known) store_soa<N>(ws.so, ws.sh_cap, slot, so);
             // point/spot: from the light along light_vec (ndt.c:211); directional: from the
             // nudged hit point along rev_light (ndt.c:238)
             // (one store of a selected VALUE: two stores from different local arrays make the compiler pick the array

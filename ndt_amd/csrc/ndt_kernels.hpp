@@ -135,6 +135,10 @@ struct TraceJob {
     // a returning atomic before it could leave, and more than it saved (profiles/experiments/README.md, round 4).
     int publish_level;
     unsigned long long publish_tag;
+    // The segmented part holds the shadow rays of the scene's lights, segment s = the s-th light that is not ambient, and the
+    // rays of a point or spot light all start AT the light (ndt.c:211): their origin is the light's position in the scene
+    // blob, not 8 N bytes a ray written by shade_emit and read back here (round 4; area lights jitter theirs: stored as before).
+    int seg_light_origins;
 };
 #define NDT_EXIT_LOG_WORDS 65536    /* per launch: 8 words {start, last batch, exit, HW_ID, out of batches, -, -, -} x 8192 wavefronts */
 #define NDT_EXIT_LOG_LAUNCHES 6
