@@ -413,6 +413,31 @@ def test_specular_disabled_path(gpu, oracle):
     assert np.abs(out - want).max() < TOL_TIGHT
 
 
+@pytest.mark.parametrize("order", [(1, 0, 3, 2), (3, 2, 1, 0), (2, 1, 0, 3)])
+def test_lights_in_any_order(gpu, oracle, order):
+    """The shadow queue has one segment per light that is not ambient, in list order, and the trace launch finds a segment's
+    light again from the scene (the rays of a point or spot light are stored without their origin: ndt_kernels.hip:
+    seg_light_origin): with the ambient light in the middle of the list or at its end, and the point / spot / directional
+    lights in every relative order, both pipelines must still give the oracle's frame (apply_lights sums in list order,
+    ndt.c:98)."""
+    from ndt_amd import load_scene
+    g = golden("zoo4d")
+    fs = load_scene(os.path.join(GOLDEN, "zoo4d.ndtscene.gz"))        # (a copy of its own: the fixture's scene is shared)
+    assert [l["type"] for l in fs.lights] == [0, 1, 3, 2]
+    fs.lights = [fs.lights[i] for i in order]
+    fs._struct = None
+    fs.finalize()
+    want, wst = oracle.render(fs, 96, 54, g.depth)
+    for pipeline in (1, 2):
+        gpu.set_option("pipeline", pipeline)
+        gpu.upload_scene(fs)
+        out, st = gpu.render(96, 54, g.depth)
+        assert np.abs(out - want).max() < TOL_TIGHT, "pipeline %d, lights %s" % (pipeline, order)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow, st.rays_ref_equiv) == (
+            wst.rays_primary, wst.rays_secondary, wst.rays_shadow, wst.rays_ref_equiv)
+    gpu.set_option("pipeline", 0)
+
+
 def test_quantize_on_device(gpu, oracle):
     import torch
     g = golden("c2_balls4d")
