@@ -217,6 +217,63 @@ def test_face_groups_list_every_face_under_axes_whose_clusters_hold_it(name):
                                                                                          pinned / max(1, int(live.sum()))))
 
 
+@pytest.mark.parametrize("name", SCENES + ["zoo9d"])
+def test_hull_frame_is_the_dual_basis_of_a_parallelotopes_edges(name):
+    """When the faces of an hcube span exactly N distinct directions (a parallelotope: ndt's hcube, sheared or not), the hull's
+    axes are the normalised dual basis of those directions -- axis_k . d_j = 0 for every direction but one -- so that a face is
+    thin (two margins) on exactly the axes of the directions it does not span, provided its own directions are orthogonal
+    (orthotope.intersect accepts only a blob around the position of a skewed face: those boxes are small on every axis)."""
+    from ndt_amd.hip import hcube_hull_box, hcube_face_boxes
+    fs = golden(name).scene
+    n = fs.dims
+    vecs = np.asarray(fs.vecs, dtype=np.float64).ravel()
+    flags = np.asarray(fs.flags)
+    refs = np.asarray(fs.obj_refs)
+    checked = 0
+    for h in hcubes(fs):
+        box = hcube_hull_box(fs, h)
+        if box is None:
+            continue
+        o = fs.objects[h]
+        dirs, faces = [], []
+        for k in range(o["n_obj"]):
+            f = fs.objects[refs[o["obj_off"] + k]]
+            m = int(flags[f["flag_off"]])
+            d = vecs[f["dir_off"]:f["dir_off"] + m * n].reshape(m, n)
+            d = d / np.linalg.norm(d, axis=1, keepdims=True)
+            mine = []
+            for u in d:
+                j = next((j for j, w in enumerate(dirs) if abs(abs(u @ w) - 1) < 1e-9), None)
+                if j is None:
+                    dirs.append(u)
+                    j = len(dirs) - 1
+                mine.append(j)
+            faces.append((mine, d))
+        if len(dirs) != n or abs(np.linalg.det(np.array(dirs))) < 1e-3:
+            continue                                    # not a parallelotope: one of the orthonormal candidate frames
+        ax = box[0]
+        cross = np.abs(ax @ np.array(dirs).T)           # [axis, direction]
+        owner = cross.argmax(axis=1)
+        assert sorted(owner.tolist()) == list(range(n))                 # every axis belongs to one direction ...
+        off = cross.copy()
+        off[np.arange(n), owner] = 0
+        assert off.max() < 1e-9                                         # ... and is orthogonal to all the others
+        fb = hcube_face_boxes(fs, h)
+        if fb is not None:
+            centre, half, live = fb
+            axis_of = {int(owner[a]): a for a in range(n)}
+            for k, (mine, d) in enumerate(faces):
+                gram = d @ d.T
+                if not live[k] or np.abs(gram - np.eye(len(d))).max() > 1e-9:
+                    continue                            # (a skewed face: a blob)
+                for j in range(n):
+                    if j not in mine:
+                        assert half[k, axis_of[j]] <= 0.02 + 2.2e-4 + 1e-12, (k, j, half[k, axis_of[j]])
+        checked += 1
+    if checked == 0:
+        pytest.skip("no parallelotope hcube with a hull box in this scene")
+
+
 def test_hull_box_of_a_non_hcube_is_an_error():
     from ndt_amd.hip import hcube_hull_box, NdtHipError
     fs = golden("c3_random4d").scene
